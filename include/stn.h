@@ -1,0 +1,120 @@
+/* stn.h — C ABI of the MI355X-native Supertonic synthesis engine (libstn.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  Each entry point names the reference
+ * interface it replaces; all paths are relative to /root/reference.
+ *
+ *   reference (ONNX Runtime C++ API)                      here
+ *   ------------------------------------------------      -------------------------------------------
+ *   Ort::Session ctor x4, loadOnnxAll                     stn_create + stn_load_dir / stn_load_synthetic
+ *     cpp/helper.cpp:776-795, loadCfgs :801-818
+ *   dp_ort_->Run          cpp/helper.cpp:512-526          stn_duration
+ *   text_enc_ort_->Run    cpp/helper.cpp:545-556          stn_text_enc
+ *   vector_est_ort_->Run  cpp/helper.cpp:620-658          stn_vector_est   (one Euler step per call)
+ *   vocoder_ort_->Run     cpp/helper.cpp:662-679          stn_vocoder
+ *   TextToSpeech::_infer  cpp/helper.cpp:469-683          stn_batch_upload + stn_batch_run + stn_batch_fetch
+ *   sampleNoisyLatent     cpp/helper.cpp:424-467          inside stn_batch_run (Philox noise, or injected)
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns STN_OK (0) or a
+ * negative error code; the message is available from stn_last_error().  Tensors are contiguous,
+ * row-major, caller-owned HOST buffers with the names / dtypes / shapes of the ONNX graph I/O
+ * (text_ids int64 [B,Lt]; masks float32 [B,1,L]; step counters float32 [B]; everything else float32).
+ * One handle = one GPU + one HIP stream; calls on one handle must be serialised by the caller; distinct
+ * handles are independent (one per GPU).  There is NO CPU fallback: without a HIP device stn_create fails.
+ */
+#ifndef STN_H
+#define STN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "stn_arch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STN_OK 0
+#define STN_ERR_INVALID (-1)      /* bad argument / shape                         */
+#define STN_ERR_DEVICE (-2)       /* HIP failure or no device                     */
+#define STN_ERR_STATE (-3)        /* call order (no model loaded, no batch, ...)  */
+#define STN_ERR_UNSUPPORTED (-4)  /* feature not available in this build          */
+#define STN_ERR_IO (-5)           /* file missing / unreadable / malformed        */
+
+#define STN_DTYPE_F32 0   /* fp32 operands, exact fp32 MFMA                        */
+#define STN_DTYPE_BF16 1  /* bf16 GEMM operands, fp32 accumulate + fp32 residual   */
+
+typedef struct stn_handle stn_handle;
+
+typedef struct stn_config {
+    int32_t device;  /* HIP device ordinal                                         */
+    int32_t dtype;   /* STN_DTYPE_*                                                */
+} stn_config;
+
+/* ---- lifetime / model load -------------------------------------------------------------------- */
+int stn_create(const stn_config* cfg, stn_handle** out);
+int stn_destroy(stn_handle* h);
+/* message of the last failure on this handle (or of the last failed stn_create when h == NULL) */
+const char* stn_last_error(const stn_handle* h);
+/* tts.json + unicode_indexer.json + the four .onnx files of `onnx_dir` (cpp/helper.cpp:784-823).
+ * Reads tts.json; weight import from .onnx initializers is not built yet -> STN_ERR_UNSUPPORTED when
+ * the graphs are present, STN_ERR_IO when the directory lacks them. */
+int stn_load_dir(stn_handle* h, const char* onnx_dir);
+/* descriptor-driven deterministic weights (no asset files needed) */
+int stn_load_synthetic(stn_handle* h, const stn_arch* arch, uint64_t seed);
+int stn_get_arch(const stn_handle* h, stn_arch* out);
+int64_t stn_param_count(const stn_handle* h);
+
+/* ---- the four former Run sites (host pointers in, host pointers out) ------------------------------ */
+int stn_duration(stn_handle* h, int B, int Lt, const int64_t* text_ids, const float* style_dp /*[B,e1,e2]*/,
+                 const float* text_mask /*[B,1,Lt]*/, float* duration /*[B] seconds*/);
+int stn_text_enc(stn_handle* h, int B, int Lt, const int64_t* text_ids, const float* style_ttl /*[B,d1,d2]*/,
+                 const float* text_mask, float* text_emb /*[B,Ce,Lt]*/);
+int stn_vector_est(stn_handle* h, int B, int L, int Lt, const float* noisy_latent /*[B,D,L]*/,
+                   const float* text_emb /*[B,Ce,Lt]*/, const float* style_ttl, const float* text_mask,
+                   const float* latent_mask /*[B,1,L]*/, const float* total_step /*[B]*/,
+                   const float* current_step /*[B], 0-based*/, float* denoised_latent /*[B,D,L]*/);
+int stn_vocoder(stn_handle* h, int B, int L, const float* latent /*[B,D,L]*/, float* wav /*[B, L*cs]*/);
+
+/* ---- fused synthesis: everything stays in HBM between stages ---------------------------------------
+ * upload: copies the batch to the GPU (text_ids, text_mask, styles; optional duration override in
+ *         seconds BEFORE the /speed division; optional utterance ids that key the noise generator so a
+ *         sharded batch draws the same noise as an unsharded one).
+ * run:    DP -> /speed -> text encoder -> noise -> total_step x estimator -> vocoder, all on the handle's
+ *         stream; returns after ENQUEUE (asynchronous) except for one tiny device->host read of the
+ *         durations when no override is given.  Call stn_sync or stn_batch_fetch to wait.
+ * fetch:  waits and copies out wav [B, L*cs] and duration [B] (after /speed, as the reference returns). */
+int stn_batch_upload(stn_handle* h, int B, int Lt, const int64_t* text_ids, const float* text_mask,
+                     const float* style_ttl, const float* style_dp, const float* duration_override_or_null,
+                     const int64_t* utt_ids_or_null);
+int stn_batch_set_noise(stn_handle* h, const float* noise /*[B,D,L]*/, int L);
+int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_seed);
+int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
+int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);
+int stn_batch_fetch_latent(stn_handle* h, float* latent /*[B,D,L]*/);
+/* device pointer of the finished waveform [B, L*cs] float32 (valid until the next upload/run) */
+int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr);
+int stn_sync(stn_handle* h);
+
+/* ---- measurement: HIP-event timing of kernel families on the engine's own stream ------------------- */
+int stn_profile_enable(stn_handle* h, int on);
+int stn_profile_reset(stn_handle* h);
+/* number of kernel families seen; then per index: name, total ms, launches, algorithmic flops and bytes */
+int stn_profile_count(stn_handle* h);
+int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,
+                    double* flops, double* bytes);
+
+/* ---- op-level entry points used by the kernel parity tests (host pointers) -------------------------- */
+int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A /*[M,K]*/, const float* W /*[N,K]*/,
+                const float* bias_or_null, int act /*0 none,1 gelu,2 silu*/, float* out /*[M,N]*/);
+int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x,
+                     const float* w /*[C,k]*/, const float* bias, const float* ln_g, const float* ln_b, float* y);
+int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
+                     const float* v, const int32_t* qlen_or_null, const int32_t* klen_or_null, int rope_mode, float* o);
+int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids_or_null,
+                 const int32_t* len_or_null, float* out);
+
+const char* stn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STN_H */

@@ -27,7 +27,7 @@ typedef struct stn_arch {
     int32_t base_chunk_size;        /* ae.base_chunk_size        512   */
     int32_t chunk_compress_factor;  /* ttl.chunk_compress_factor 6     */
     int32_t latent_dim;             /* ttl.latent_dim            24    */
-    /* token / style geometry (unicode_indexer.json, voice_styles/*.json) */
+    /* token / style geometry (unicode_indexer.json, voice-style JSON files) */
     int32_t vocab_size;             /* token ids in [0, vocab_size)            */
     int32_t n_style_ttl, d_style_ttl; /* style_ttl [B, 50, 256]                */
     int32_t n_style_dp, d_style_dp;   /* style_dp  [B, 8, 16]                  */

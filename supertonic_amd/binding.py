@@ -1,0 +1,270 @@
+"""ctypes binding of include/stn.h (libstn.so).  The library is the product path: if it is missing or
+no HIP device is present, loading / Engine() raises — there is no CPU fallback."""
+import ctypes
+import os
+
+import numpy as np
+
+from .arch import StnArch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstn.so")
+_LIB = None
+
+F32, BF16 = 0, 1
+_DTYPES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, F32: F32, BF16: BF16}
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+class StnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"stn error {code}: {msg}")
+        self.code = code
+
+
+class StnConfig(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("dtype", ctypes.c_int32)]
+
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+def load():
+    """Load libstn.so (built by `make` / __graft_entry__.build()).  Raises if it is not there."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950); "
+                                "the engine has no fallback path")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cu64, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
+    L.stn_version.restype = ctypes.c_char_p
+    L.stn_create.argtypes = [ctypes.POINTER(StnConfig), ctypes.POINTER(vp)]
+    L.stn_destroy.argtypes = [vp]
+    L.stn_last_error.restype = ctypes.c_char_p
+    L.stn_last_error.argtypes = [vp]
+    L.stn_load_dir.argtypes = [vp, ctypes.c_char_p]
+    L.stn_load_synthetic.argtypes = [vp, ctypes.POINTER(StnArch), cu64]
+    L.stn_get_arch.argtypes = [vp, ctypes.POINTER(StnArch)]
+    L.stn_param_count.restype = ctypes.c_int64
+    L.stn_param_count.argtypes = [vp]
+    L.stn_duration.argtypes = [vp, ci, ci, _i64p, _f32p, _f32p, _f32p]
+    L.stn_text_enc.argtypes = [vp, ci, ci, _i64p, _f32p, _f32p, _f32p]
+    L.stn_vector_est.argtypes = [vp, ci, ci, ci] + [_f32p] * 8
+    L.stn_vocoder.argtypes = [vp, ci, ci, _f32p, _f32p]
+    L.stn_batch_upload.argtypes = [vp, ci, ci, _i64p, _f32p, _f32p, _f32p, vp, vp]
+    L.stn_batch_set_noise.argtypes = [vp, _f32p, ci]
+    L.stn_batch_run.argtypes = [vp, ci, cf, cu64]
+    L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
+    L.stn_batch_fetch.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
+    L.stn_batch_wav_device_ptr.argtypes = [vp, ctypes.POINTER(vp)]
+    L.stn_sync.argtypes = [vp]
+    L.stn_profile_enable.argtypes = [vp, ci]
+    L.stn_profile_reset.argtypes = [vp]
+    L.stn_profile_count.argtypes = [vp]
+    L.stn_profile_get.argtypes = [vp, ci, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double),
+                                  ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
+                                  ctypes.POINTER(ctypes.c_double)]
+    L.stn_op_gemm.argtypes = [vp, ci, ci, ci, ci, _f32p, _f32p, vp, ci, _f32p]
+    L.stn_op_dwconv_ln.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+    L.stn_op_attention.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, vp, vp, ci, _f32p]
+    L.stn_op_randn.argtypes = [vp, cu64, ci, ci, ci, vp, vp, _f32p]
+    _LIB = L
+    return L
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _opt(a, dt):
+    if a is None:
+        return None, None
+    arr = _c(a, dt)
+    return arr, arr.ctypes.data
+
+
+class Engine:
+    """One GPU + one HIP stream.  Mirrors the four ONNX sessions of the reference's TextToSpeech
+    (/root/reference/cpp/helper.cpp:404-422) behind the C ABI."""
+
+    def __init__(self, device=0, dtype="bf16"):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        cfg = StnConfig(device, _DTYPES[dtype])
+        rc = self._lib.stn_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.stn_last_error(None).decode()
+            self._h = None
+            raise StnError(rc, msg)
+        self.dtype = _DTYPES[dtype]
+        self.arch = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise StnError(rc, self._lib.stn_last_error(self._h).decode())
+        return rc
+
+    # ---- model -------------------------------------------------------------------------------
+    def load_synthetic(self, arch: StnArch, seed: int = 7):
+        self._ck(self._lib.stn_load_synthetic(self._h, ctypes.byref(arch), seed))
+        self.arch = arch
+
+    def load_dir(self, onnx_dir: str):
+        self._ck(self._lib.stn_load_dir(self._h, onnx_dir.encode()))
+
+    @property
+    def param_count(self):
+        return self._lib.stn_param_count(self._h)
+
+    # ---- the four former Run sites ----------------------------------------------------------------
+    def duration(self, text_ids, style_dp, text_mask):
+        B, Lt = text_ids.shape
+        out = np.empty(B, np.float32)
+        self._ck(self._lib.stn_duration(self._h, B, Lt, _c(text_ids, np.int64), _c(style_dp, np.float32),
+                                        _c(text_mask, np.float32), out))
+        return out
+
+    def text_enc(self, text_ids, style_ttl, text_mask):
+        B, Lt = text_ids.shape
+        out = np.empty((B, self.arch.te_out_dim, Lt), np.float32)
+        self._ck(self._lib.stn_text_enc(self._h, B, Lt, _c(text_ids, np.int64), _c(style_ttl, np.float32),
+                                        _c(text_mask, np.float32), out))
+        return out
+
+    def vector_est(self, noisy, text_emb, style_ttl, text_mask, latent_mask, total_step, current_step):
+        B, D, L = noisy.shape
+        Lt = text_emb.shape[2]
+        out = np.empty((B, D, L), np.float32)
+        self._ck(self._lib.stn_vector_est(self._h, B, L, Lt, _c(noisy, np.float32), _c(text_emb, np.float32),
+                                          _c(style_ttl, np.float32), _c(text_mask, np.float32),
+                                          _c(latent_mask, np.float32), _c(total_step, np.float32),
+                                          _c(current_step, np.float32), out))
+        return out
+
+    def vocoder(self, latent):
+        B, D, L = latent.shape
+        out = np.empty((B, L * self.arch.chunk_size), np.float32)
+        self._ck(self._lib.stn_vocoder(self._h, B, L, _c(latent, np.float32), out))
+        return out
+
+    # ---- fused, HBM-resident synthesis ----------------------------------------------------------------
+    def batch_upload(self, text_ids, text_mask, style_ttl, style_dp, duration_override=None, utt_ids=None):
+        B, Lt = text_ids.shape
+        _d, dptr = _opt(duration_override, np.float32)
+        _u, uptr = _opt(utt_ids, np.int64)
+        self._ck(self._lib.stn_batch_upload(self._h, B, Lt, _c(text_ids, np.int64), _c(text_mask, np.float32),
+                                            _c(style_ttl, np.float32), _c(style_dp, np.float32), dptr, uptr))
+
+    def batch_set_noise(self, noise):
+        noise = _c(noise, np.float32)
+        self._ck(self._lib.stn_batch_set_noise(self._h, noise, noise.shape[2]))
+
+    def batch_run(self, total_step=5, speed=1.05, noise_seed=1234):
+        self._ck(self._lib.stn_batch_run(self._h, total_step, speed, noise_seed))
+
+    def batch_dims(self):
+        B, L, W = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        self._ck(self._lib.stn_batch_dims(self._h, ctypes.byref(B), ctypes.byref(L), ctypes.byref(W)))
+        return B.value, L.value, W.value
+
+    def batch_fetch(self, want_wav=True):
+        B, L, W = self.batch_dims()
+        dur = np.empty(B, np.float32)
+        wav = np.empty((B, W), np.float32) if want_wav else None
+        self._ck(self._lib.stn_batch_fetch(self._h, wav.ctypes.data if want_wav else None, B * W if want_wav else 0,
+                                           dur.ctypes.data))
+        return wav, dur
+
+    def batch_fetch_latent(self):
+        B, L, _ = self.batch_dims()
+        out = np.empty((B, self.arch.latent_channels, L), np.float32)
+        self._ck(self._lib.stn_batch_fetch_latent(self._h, out))
+        return out
+
+    def batch_wav_device_ptr(self):
+        p = ctypes.c_void_p()
+        self._ck(self._lib.stn_batch_wav_device_ptr(self._h, ctypes.byref(p)))
+        return p.value
+
+    def sync(self):
+        self._ck(self._lib.stn_sync(self._h))
+
+    def synthesize(self, text_ids, text_mask, style_ttl, style_dp, total_step=5, speed=1.05, noise=None,
+                   duration_override=None, noise_seed=1234, utt_ids=None):
+        """TextToSpeech::_infer (/root/reference/cpp/helper.cpp:469-683) -> (wav [B, L*cs], duration [B])."""
+        self.batch_upload(text_ids, text_mask, style_ttl, style_dp, duration_override, utt_ids)
+        if noise is not None:
+            self.batch_set_noise(noise)
+        self.batch_run(total_step, speed, noise_seed)
+        return self.batch_fetch()
+
+    # ---- measurement -----------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ck(self._lib.stn_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self._lib.stn_profile_reset(self._h))
+
+    def profile(self):
+        """{kernel family: dict(ms, launches, flops, bytes)} measured with HIP events on the engine's stream."""
+        n = self._ck(self._lib.stn_profile_count(self._h))
+        out = {}
+        name = ctypes.create_string_buffer(64)
+        ms, fl, by, la = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        for i in range(n):
+            self._ck(self._lib.stn_profile_get(self._h, i, name, 64, ctypes.byref(ms), ctypes.byref(la),
+                                               ctypes.byref(fl), ctypes.byref(by)))
+            out[name.value.decode()] = dict(ms=ms.value, launches=la.value, flops=fl.value, bytes=by.value)
+        return out
+
+    # ---- op-level (kernel parity tests) ----------------------------------------------------------------
+    def op_gemm(self, A, W, bias=None, act=ACT_NONE, dtype=None):
+        M, K = A.shape
+        N = W.shape[0]
+        out = np.empty((M, N), np.float32)
+        _b, bptr = _opt(bias, np.float32)
+        self._ck(self._lib.stn_op_gemm(self._h, self.dtype if dtype is None else _DTYPES[dtype], M, N, K,
+                                       _c(A, np.float32), _c(W, np.float32), bptr, act, out))
+        return out
+
+    def op_dwconv_ln(self, x, w, bias, g, b, dil, dtype=None):
+        B, L, C = x.shape
+        k = w.shape[1]
+        y = np.empty((B, L, C), np.float32)
+        self._ck(self._lib.stn_op_dwconv_ln(self._h, self.dtype if dtype is None else _DTYPES[dtype], B, L, C, k, dil,
+                                            _c(x, np.float32), _c(w, np.float32), _c(bias, np.float32),
+                                            _c(g, np.float32), _c(b, np.float32), y))
+        return y
+
+    def op_attention(self, q, k, v, H, qlen=None, klen=None, rope_mode=-1, dtype=None):
+        B, Lq, C = q.shape
+        Lk = k.shape[1]
+        o = np.empty((B, Lq, C), np.float32)
+        _q, qp = _opt(qlen, np.int32)
+        _k, kp = _opt(klen, np.int32)
+        self._ck(self._lib.stn_op_attention(self._h, self.dtype if dtype is None else _DTYPES[dtype], B, Lq, Lk, H,
+                                            C // H, _c(q, np.float32), _c(k, np.float32), _c(v, np.float32), qp, kp,
+                                            rope_mode, o))
+        return o
+
+    def op_randn(self, seed, B, D, L, utt_ids=None, length=None):
+        out = np.empty((B, D, L), np.float32)
+        _u, up = _opt(utt_ids, np.int64)
+        _l, lp = _opt(length, np.int32)
+        self._ck(self._lib.stn_op_randn(self._h, seed, B, D, L, up, lp, out))
+        return out

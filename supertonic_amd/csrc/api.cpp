@@ -1,0 +1,184 @@
+// api.cpp — the C ABI of include/stn.h over stn::Engine.  No exception leaves this file.
+#include "../../include/stn.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "engine.hpp"
+
+struct stn_handle {
+    stn::Engine* eng = nullptr;
+    std::string err;
+    std::vector<std::pair<std::string, stn::KernelStat>> prof;
+};
+
+static thread_local std::string g_create_err;
+
+#define STN_TRY(h, body)                                             \
+    if (!(h)) return STN_ERR_INVALID;                                \
+    try {                                                            \
+        body;                                                        \
+        return STN_OK;                                               \
+    } catch (const std::invalid_argument& e) {                       \
+        (h)->err = e.what();                                         \
+        return STN_ERR_INVALID;                                      \
+    } catch (const std::exception& e) {                              \
+        (h)->err = e.what();                                         \
+        return (h)->err.rfind("HIP error", 0) == 0 ? STN_ERR_DEVICE : STN_ERR_STATE; \
+    } catch (...) {                                                  \
+        (h)->err = "unknown failure";                                \
+        return STN_ERR_DEVICE;                                       \
+    }
+
+static void need(bool ok, const char* what) {
+    if (!ok) throw std::invalid_argument(what);
+}
+static void need_model(stn_handle* h) {
+    if (!h->eng->loaded()) throw std::runtime_error("no model loaded: call stn_load_synthetic or stn_load_dir first");
+}
+
+extern "C" {
+
+const char* stn_version(void) { return "supertonic_amd 0.1 (gfx950)"; }
+
+int stn_create(const stn_config* cfg, stn_handle** out) {
+    if (!cfg || !out) { g_create_err = "stn_create: null argument"; return STN_ERR_INVALID; }
+    *out = nullptr;
+    try {
+        stn_handle* h = new stn_handle;
+        h->eng = new stn::Engine(cfg->device, cfg->dtype);
+        *out = h;
+        return STN_OK;
+    } catch (const std::exception& e) {
+        g_create_err = e.what();
+        return STN_ERR_DEVICE;
+    }
+}
+int stn_destroy(stn_handle* h) {
+    if (!h) return STN_OK;
+    try { delete h->eng; } catch (...) {}
+    delete h;
+    return STN_OK;
+}
+const char* stn_last_error(const stn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int stn_load_synthetic(stn_handle* h, const stn_arch* arch, uint64_t seed) {
+    STN_TRY(h, { need(arch != nullptr, "arch is null"); h->eng->load_synthetic(*arch, seed); })
+}
+int stn_load_dir(stn_handle* h, const char* onnx_dir) {
+    if (!h) return STN_ERR_INVALID;
+    if (!onnx_dir) { h->err = "onnx_dir is null"; return STN_ERR_INVALID; }
+    static const char* files[] = {"tts.json", "unicode_indexer.json", "duration_predictor.onnx", "text_encoder.onnx",
+                                  "vector_estimator.onnx", "vocoder.onnx"};
+    for (const char* f : files) {
+        std::ifstream in(std::string(onnx_dir) + "/" + f, std::ios::binary);
+        if (!in.is_open()) { h->err = std::string("Failed to open ") + onnx_dir + "/" + f; return STN_ERR_IO; }
+    }
+    h->err = "ONNX initializer import is not built yet (SURVEY.md §8 row f1); use stn_load_synthetic";
+    return STN_ERR_UNSUPPORTED;
+}
+int stn_get_arch(const stn_handle* h, stn_arch* out) {
+    if (!h || !out) return STN_ERR_INVALID;
+    *out = h->eng->arch();
+    return STN_OK;
+}
+int64_t stn_param_count(const stn_handle* h) { return h ? h->eng->param_count() : 0; }
+
+int stn_duration(stn_handle* h, int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur) {
+    STN_TRY(h, { need_model(h); need(B > 0 && Lt > 0 && ids && style_dp && text_mask && dur, "stn_duration: bad argument");
+                 h->eng->duration(B, Lt, ids, style_dp, text_mask, dur); })
+}
+int stn_text_enc(stn_handle* h, int B, int Lt, const int64_t* ids, const float* style_ttl, const float* text_mask, float* emb) {
+    STN_TRY(h, { need_model(h); need(B > 0 && Lt > 0 && ids && style_ttl && text_mask && emb, "stn_text_enc: bad argument");
+                 h->eng->text_enc(B, Lt, ids, style_ttl, text_mask, emb); })
+}
+int stn_vector_est(stn_handle* h, int B, int L, int Lt, const float* noisy, const float* text_emb, const float* style_ttl,
+                   const float* text_mask, const float* latent_mask, const float* total_step, const float* current_step,
+                   float* out) {
+    STN_TRY(h, { need_model(h);
+                 need(B > 0 && L > 0 && Lt > 0 && noisy && text_emb && style_ttl && text_mask && latent_mask && total_step && current_step && out,
+                      "stn_vector_est: bad argument");
+                 for (int b = 0; b < B; ++b) need(total_step[b] >= 1.0f, "stn_vector_est: total_step must be >= 1");
+                 h->eng->vector_est(B, L, Lt, noisy, text_emb, style_ttl, text_mask, latent_mask, total_step, current_step, out); })
+}
+int stn_vocoder(stn_handle* h, int B, int L, const float* latent, float* wav) {
+    STN_TRY(h, { need_model(h); need(B > 0 && L > 0 && latent && wav, "stn_vocoder: bad argument"); h->eng->vocoder(B, L, latent, wav); })
+}
+
+int stn_batch_upload(stn_handle* h, int B, int Lt, const int64_t* ids, const float* text_mask, const float* style_ttl,
+                     const float* style_dp, const float* dur_override, const int64_t* utt_ids) {
+    STN_TRY(h, { need_model(h); need(B > 0 && Lt > 0 && ids && text_mask && style_ttl && style_dp, "stn_batch_upload: bad argument");
+                 if (dur_override) for (int b = 0; b < B; ++b) need(dur_override[b] > 0.f, "duration override must be > 0");
+                 h->eng->batch_upload(B, Lt, ids, text_mask, style_ttl, style_dp, dur_override, utt_ids); })
+}
+int stn_batch_set_noise(stn_handle* h, const float* noise, int L) {
+    STN_TRY(h, { need(noise != nullptr, "noise is null"); h->eng->batch_set_noise(noise, L); })
+}
+int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_seed) {
+    STN_TRY(h, { need_model(h); need(total_step >= 1, "total_step must be >= 1"); need(speed > 0.f, "speed must be > 0");
+                 h->eng->batch_run(total_step, speed, noise_seed); })
+}
+int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len) {
+    if (!h) return STN_ERR_INVALID;
+    const auto& b = h->eng->batch();
+    const auto& a = h->eng->arch();
+    if (B) *B = b.B;
+    if (L) *L = b.L;
+    if (wav_len) *wav_len = (int64_t)b.L * a.base_chunk_size * a.chunk_compress_factor;
+    return STN_OK;
+}
+int stn_batch_fetch(stn_handle* h, float* wav, size_t cap, float* duration) {
+    STN_TRY(h, { need(h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch(wav, cap, duration); })
+}
+int stn_batch_fetch_latent(stn_handle* h, float* latent) {
+    STN_TRY(h, { need(latent && h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_latent(latent); })
+}
+int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr) {
+    if (!h || !ptr) return STN_ERR_INVALID;
+    *ptr = h->eng->batch().wav;
+    return *ptr ? STN_OK : STN_ERR_STATE;
+}
+int stn_sync(stn_handle* h) { STN_TRY(h, { h->eng->sync(); }) }
+
+int stn_profile_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->profile_enable(on != 0); }) }
+int stn_profile_reset(stn_handle* h) { STN_TRY(h, { h->eng->profile_reset(); h->prof.clear(); }) }
+int stn_profile_count(stn_handle* h) {
+    if (!h) return STN_ERR_INVALID;
+    try { h->prof = h->eng->profile_collect(); } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_DEVICE; }
+    return (int)h->prof.size();
+}
+int stn_profile_get(stn_handle* h, int idx, char* name, size_t cap, double* ms, int64_t* launches, double* flops, double* bytes) {
+    if (!h || idx < 0 || idx >= (int)h->prof.size()) return STN_ERR_INVALID;
+    const auto& p = h->prof[idx];
+    if (name && cap) { std::snprintf(name, cap, "%s", p.first.c_str()); }
+    if (ms) *ms = p.second.ms;
+    if (launches) *launches = p.second.launches;
+    if (flops) *flops = p.second.flops;
+    if (bytes) *bytes = p.second.bytes;
+    return STN_OK;
+}
+
+int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A, const float* W, const float* bias, int act, float* out) {
+    STN_TRY(h, { need(M > 0 && N > 0 && K > 0 && A && W && out, "stn_op_gemm: bad argument");
+                 need(K % (dtype == STN_DTYPE_BF16 ? 8 : 4) == 0, "stn_op_gemm: K must be a multiple of 8 (bf16) / 4 (f32)");
+                 h->eng->op_gemm(dtype, M, N, K, A, W, bias, act, out); })
+}
+int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w,
+                     const float* bias, const float* g, const float* b, float* y) {
+    STN_TRY(h, { need(B > 0 && L > 0 && C > 0 && C % 4 == 0 && C <= 1024 && k > 0 && (k & 1) && dil > 0 && x && w && bias && g && b && y,
+                      "stn_op_dwconv_ln: bad argument");
+                 h->eng->op_dwconv_ln(dtype, B, L, C, k, dil, x, w, bias, g, b, y); })
+}
+int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
+                     const float* v, const int32_t* qlen, const int32_t* klen, int rope_mode, float* o) {
+    STN_TRY(h, { need(B > 0 && Lq > 0 && Lk > 0 && H > 0 && dh >= 8 && dh % 8 == 0 && dh <= 96 && q && k && v && o,
+                      "stn_op_attention: bad argument");
+                 h->eng->op_attention(dtype, B, Lq, Lk, H, dh, q, k, v, qlen, klen, rope_mode, o); })
+}
+int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int32_t* len, float* out) {
+    STN_TRY(h, { need(B > 0 && D > 0 && L > 0 && out, "stn_op_randn: bad argument"); h->eng->op_randn(seed, B, D, L, utt_ids, len, out); })
+}
+
+}  // extern "C"

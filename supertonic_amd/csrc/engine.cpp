@@ -1,0 +1,914 @@
+// engine.cpp — weights, workspace and the four stage executors (see engine.hpp).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace stn {
+
+// =================================================================================================
+// Arena
+// =================================================================================================
+Arena::~Arena() {
+    for (auto& c : chunks_) (void)hipFree(c.p);
+}
+size_t Arena::capacity() const {
+    size_t t = 0;
+    for (auto& c : chunks_) t += c.cap;
+    return t;
+}
+void* Arena::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    for (;;) {
+        if (cur_ < chunks_.size()) {
+            Chunk& c = chunks_[cur_];
+            if (off_ + bytes <= c.cap) {
+                void* p = c.p + off_;
+                off_ += bytes;
+                return p;
+            }
+            ++cur_;
+            off_ = 0;
+            continue;
+        }
+        Chunk c;
+        c.cap = std::max(bytes, size_t(256) << 20);
+        STN_HIP(hipMalloc(reinterpret_cast<void**>(&c.p), c.cap));
+        chunks_.push_back(c);
+    }
+}
+
+// =================================================================================================
+// deterministic synthetic weights (spec shared with the oracle by definition, not by code):
+//   value(name, i) = offs + scale * u,  u = top 24 bits of mix64(mix64(seed ^ fnv1a(name)) + i) / 2^23 - 1
+// =================================================================================================
+namespace {
+enum Kind { K_W, K_BIAS, K_LN_G, K_LN_B, K_LSCALE, K_EMB };
+
+uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ULL;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ULL; }
+    return h;
+}
+uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+std::vector<float> synth(uint64_t seed, const std::string& name, Kind kind, int rows, int cols, float gain) {
+    const size_t n = (size_t)rows * cols;
+    std::vector<float> v(n);
+    float scale = 1.f, offs = 0.f;
+    switch (kind) {
+        case K_W: scale = std::sqrt(3.0f / (float)cols) * gain; break;
+        case K_BIAS: scale = 0.05f; break;
+        case K_LN_G: scale = 0.1f; offs = 1.0f; break;
+        case K_LN_B: scale = 0.05f; break;
+        case K_LSCALE: scale = 0.1f; offs = 0.2f; break;
+        case K_EMB: scale = std::sqrt(3.0f); break;
+    }
+    const uint64_t base = mix64(seed ^ fnv1a(name));
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t h = mix64(base + i);
+        const float u = (float)(h >> 40) * (1.0f / 8388608.0f) - 1.0f;
+        v[i] = offs + scale * u;
+    }
+    return v;
+}
+uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // RNE (weights are finite)
+}
+}  // namespace
+
+// =================================================================================================
+// Engine: construction / weights
+// =================================================================================================
+Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
+    if (dtype != F32 && dtype != BF16) throw std::runtime_error("dtype must be 0 (fp32) or 1 (bf16)");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the engine has no CPU fallback");
+    if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
+    STN_HIP(hipSetDevice(device));
+    STN_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+}
+
+void Engine::free_weights() {
+    for (void* p : owned_) (void)hipFree(p);
+    owned_.clear();
+    w_.clear();
+    loaded_ = false;
+    params_ = 0;
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (s_) (void)hipStreamSynchronize(s_);
+    free_weights();
+    for (void* p : batch_owned_) (void)hipFree(p);
+    for (auto& sp : spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
+    if (s_) (void)hipStreamDestroy(s_);
+}
+
+DevTensor& Engine::tensor(const std::string& name) {
+    auto it = w_.find(name);
+    if (it == w_.end()) throw std::runtime_error("unknown weight tensor: " + name);
+    return it->second;
+}
+Linear Engine::linear(const std::string& p) {
+    Linear l;
+    l.w = tensor(p + ".w");
+    l.b = tensor(p + ".b").f32;
+    l.N = l.w.rows;
+    l.K = l.w.cols;
+    return l;
+}
+LNorm Engine::lnorm(const std::string& p) { return LNorm{tensor(p + ".g").f32, tensor(p + ".b").f32}; }
+ConvNeXt Engine::convnext_w(const std::string& p) {
+    ConvNeXt c;
+    c.dw_t = tensor(p + ".dw.wt").f32;
+    c.dw_b = tensor(p + ".dw.b").f32;
+    c.ln = lnorm(p + ".ln");
+    c.pw1 = linear(p + ".pw1");
+    c.pw2 = linear(p + ".pw2");
+    c.gamma = tensor(p + ".gamma").f32;
+    return c;
+}
+Attn Engine::attn_w(const std::string& p, bool self) {
+    Attn a;
+    a.ln = lnorm(p + ".ln");
+    a.q = linear(p + ".q");
+    a.kv = linear(p + ".kv");
+    if (self) a.qkv = linear(p + ".qkv");
+    a.o = linear(p + ".o");
+    return a;
+}
+
+void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
+    STN_HIP(hipSetDevice(device_));
+    sync();
+    free_weights();
+    a_ = a;
+    const int D = a.latent_dim * a.chunk_compress_factor;
+    if (a.te_dim % a.te_heads || a.dp_dim % a.dp_heads || a.ve_dim % a.ve_heads)
+        throw std::runtime_error("model width must be divisible by the head count");
+    if (a.vo_blocks > STN_MAX_VO_BLOCKS) throw std::runtime_error("vo_blocks exceeds STN_MAX_VO_BLOCKS");
+
+    std::unordered_map<std::string, std::vector<float>> host;  // canonical copies kept for derived tensors
+    auto upload = [&](const std::string& name, const std::vector<float>& v, int rows, int cols, bool want_bf16) {
+        DevTensor t;
+        t.rows = rows;
+        t.cols = cols;
+        STN_HIP(hipMalloc(reinterpret_cast<void**>(&t.f32), std::max<size_t>(v.size(), 4) * 4));
+        owned_.push_back(t.f32);
+        STN_HIP(hipMemcpy(t.f32, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+        if (want_bf16) {
+            std::vector<uint16_t> h(v.size());
+            for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+            STN_HIP(hipMalloc(reinterpret_cast<void**>(&t.bf16), std::max<size_t>(v.size(), 8) * 2));
+            owned_.push_back(t.bf16);
+            STN_HIP(hipMemcpy(t.bf16, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        w_[name] = t;
+    };
+    auto decl = [&](const std::string& name, Kind kind, int rows, int cols, float gain, bool matrix, bool keep) {
+        std::vector<float> v = synth(seed, name, kind, rows, cols, gain);
+        params_ += (int64_t)v.size();
+        upload(name, v, rows, cols, matrix);
+        if (keep) host[name] = std::move(v);
+    };
+    auto decl_linear = [&](const std::string& p, int out, int in, float gain, bool keep) {
+        decl(p + ".w", K_W, out, in, gain, true, keep);
+        decl(p + ".b", K_BIAS, 1, out, 1.f, false, keep);
+    };
+    auto decl_ln = [&](const std::string& p, int c) {
+        decl(p + ".g", K_LN_G, 1, c, 1.f, false, false);
+        decl(p + ".b", K_LN_B, 1, c, 1.f, false, false);
+    };
+    auto decl_convnext = [&](const std::string& p, int c, int hid, int k) {
+        std::vector<float> w = synth(seed, p + ".dw.w", K_W, c, k, 1.f);  // canonical [C][k]
+        params_ += (int64_t)w.size();
+        std::vector<float> wt((size_t)c * k);                            // stored [k][C]: coalesced per tap
+        for (int ch = 0; ch < c; ++ch) for (int j = 0; j < k; ++j) wt[(size_t)j * c + ch] = w[(size_t)ch * k + j];
+        upload(p + ".dw.wt", wt, k, c, false);
+        decl(p + ".dw.b", K_BIAS, 1, c, 1.f, false, false);
+        decl_ln(p + ".ln", c);
+        decl_linear(p + ".pw1", hid, c, 1.f, false);
+        decl_linear(p + ".pw2", c, hid, 1.f, false);
+        decl(p + ".gamma", K_LSCALE, 1, c, 1.f, false, false);
+    };
+    // concat rows of several [rows_i][cols] matrices (and their biases) into one GEMM operand
+    auto concat = [&](const std::string& name, const std::vector<std::string>& parts, int cols) {
+        std::vector<float> w, b;
+        for (auto& p : parts) {
+            auto& pw = host.at(p + ".w");
+            auto& pb = host.at(p + ".b");
+            w.insert(w.end(), pw.begin(), pw.end());
+            b.insert(b.end(), pb.begin(), pb.end());
+        }
+        upload(name + ".w", w, (int)(w.size() / cols), cols, true);
+        upload(name + ".b", b, 1, (int)b.size(), false);
+    };
+    auto decl_attn = [&](const std::string& p, int c, int cctx, bool self) {
+        decl_ln(p + ".ln", c);
+        decl_linear(p + ".q", c, c, 1.f, true);
+        decl_linear(p + ".k", c, cctx, 1.f, true);
+        decl_linear(p + ".v", c, cctx, 1.f, true);
+        decl_linear(p + ".o", c, c, 1.f, false);
+        concat(p + ".kv", {p + ".k", p + ".v"}, cctx);
+        if (self) concat(p + ".qkv", {p + ".q", p + ".k", p + ".v"}, c);
+    };
+    auto S = [](const char* fmt, int i, int j = 0) { char b[64]; snprintf(b, sizeof b, fmt, i, j); return std::string(b); };
+
+    // duration predictor
+    decl("dp.emb", K_EMB, a.vocab_size, a.dp_dim, 1.f, false, false);
+    for (int i = 0; i < a.dp_conv_blocks; ++i) decl_convnext(S("dp.conv%d", i), a.dp_dim, a.dp_hidden, a.dp_kernel);
+    decl_attn("dp.st", a.dp_dim, a.d_style_dp, false);
+    decl_ln("dp.out_ln", a.dp_dim);
+    decl_linear("dp.fc1", a.dp_dim, a.dp_dim, 1.f, false);
+    decl_linear("dp.fc2", 1, a.dp_dim, 1.f, false);
+    // text encoder
+    decl("te.emb", K_EMB, a.vocab_size, a.te_dim, 1.f, false, false);
+    for (int i = 0; i < a.te_conv_blocks; ++i) decl_convnext(S("te.conv%d", i), a.te_dim, a.te_hidden, a.te_kernel);
+    for (int i = 0; i < a.te_attn_blocks; ++i) {
+        decl_attn(S("te.sa%d", i), a.te_dim, a.te_dim, true);
+        decl_ln(S("te.sa%d.ffn_ln", i), a.te_dim);
+        decl_linear(S("te.sa%d.ffn1", i), a.te_ffn, a.te_dim, 1.f, false);
+        decl_linear(S("te.sa%d.ffn2", i), a.te_dim, a.te_ffn, 1.f, false);
+    }
+    for (int i = 0; i < a.te_style_blocks; ++i) decl_attn(S("te.st%d", i), a.te_dim, a.d_style_ttl, false);
+    decl_ln("te.out_ln", a.te_dim);
+    decl_linear("te.proj", a.te_out_dim, a.te_dim, 1.f, false);
+    // vector estimator
+    decl_linear("ve.in", a.ve_dim, D, 1.f, false);
+    decl_linear("ve.t1", a.ve_dim, a.ve_time_dim, 1.f, false);
+    decl_linear("ve.t2", a.ve_dim, a.ve_dim, 1.f, false);
+    std::vector<std::string> time_parts, text_k, style_k;
+    for (int b = 0; b < a.ve_main_blocks; ++b) {
+        for (int j = 0; j < a.ve_dilated; ++j) decl_convnext(S("ve.m%d.dil%d", b, j), a.ve_dim, a.ve_hidden, a.ve_kernel);
+        decl_linear(S("ve.m%d.time", b), a.ve_dim, a.ve_dim, 1.f, true);
+        time_parts.push_back(S("ve.m%d.time", b));
+        decl_convnext(S("ve.m%d.cn_a", b), a.ve_dim, a.ve_hidden, a.ve_kernel);
+        decl_attn(S("ve.m%d.text", b), a.ve_dim, a.te_out_dim, false);
+        text_k.push_back(S("ve.m%d.text.k", b)); text_k.push_back(S("ve.m%d.text.v", b));
+        decl_convnext(S("ve.m%d.cn_b", b), a.ve_dim, a.ve_hidden, a.ve_kernel);
+        decl_attn(S("ve.m%d.style", b), a.ve_dim, a.d_style_ttl, false);
+        style_k.push_back(S("ve.m%d.style.k", b)); style_k.push_back(S("ve.m%d.style.v", b));
+    }
+    concat("ve.time_all", time_parts, a.ve_dim);       // [nb*C][C]
+    concat("ve.text_kv_all", text_k, a.te_out_dim);    // [nb*2C][Ce]: block b -> K rows b*2C.., V rows b*2C+C..
+    concat("ve.style_kv_all", style_k, a.d_style_ttl); // [nb*2C][Ds]
+    for (int j = 0; j < a.ve_tail_blocks; ++j) decl_convnext(S("ve.tail%d", j), a.ve_dim, a.ve_hidden, a.ve_kernel);
+    decl_ln("ve.out_ln", a.ve_dim);
+    decl_linear("ve.out", D, a.ve_dim, 1.f, false);
+    // vocoder
+    {
+        const int ld = a.latent_dim, k = a.vo_in_kernel, C = a.vo_dim;
+        std::vector<float> w = synth(seed, "vo.in.w", K_W, C, ld * k, 1.f);  // canonical [C][ld][k]
+        params_ += (int64_t)w.size();
+        std::vector<float> wt(w.size());                                     // stored [ld*k][C]
+        for (int co = 0; co < C; ++co) for (int i = 0; i < ld * k; ++i) wt[(size_t)i * C + co] = w[(size_t)co * ld * k + i];
+        upload("vo.in.wt", wt, ld * k, C, false);
+        decl("vo.in.b", K_BIAS, 1, C, 1.f, false, false);
+    }
+    for (int i = 0; i < a.vo_blocks; ++i) decl_convnext(S("vo.blk%d", i), a.vo_dim, a.vo_hidden, a.vo_kernel);
+    decl_ln("vo.out_ln", a.vo_dim);
+    decl_linear("vo.head", a.base_chunk_size, a.vo_dim, a.head_gain, false);
+    loaded_ = true;
+}
+
+// =================================================================================================
+// profiling
+// =================================================================================================
+void Engine::prof_begin(const char* tag, double flops, double bytes) {
+    if (!prof_on_ || spans_.size() > 200000) return;
+    ProfSpan sp;
+    sp.tag = tag;
+    sp.flops = flops;
+    sp.bytes = bytes;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); }
+        else STN_HIP(hipEventCreate(&e));
+        return e;
+    };
+    sp.a = get();
+    sp.b = get();
+    STN_HIP(hipEventRecord(sp.a, s_));
+    spans_.push_back(sp);
+}
+void Engine::prof_end() {
+    if (!prof_on_ || spans_.empty()) return;
+    STN_HIP(hipEventRecord(spans_.back().b, s_));
+}
+void Engine::profile_reset() {
+    sync();
+    for (auto& sp : spans_) { ev_pool_.push_back(sp.a); ev_pool_.push_back(sp.b); }
+    spans_.clear();
+}
+std::vector<std::pair<std::string, KernelStat>> Engine::profile_collect() {
+    sync();
+    std::unordered_map<std::string, KernelStat> acc;
+    std::vector<std::string> order;
+    for (auto& sp : spans_) {
+        float ms = 0.f;
+        STN_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        auto it = acc.find(sp.tag);
+        if (it == acc.end()) { order.push_back(sp.tag); it = acc.emplace(sp.tag, KernelStat{}).first; }
+        it->second.ms += ms;
+        it->second.launches += 1;
+        it->second.flops += sp.flops;
+        it->second.bytes += sp.bytes;
+    }
+    std::vector<std::pair<std::string, KernelStat>> out;
+    for (auto& t : order) out.emplace_back(t, acc[t]);
+    return out;
+}
+
+// =================================================================================================
+// building blocks
+// =================================================================================================
+void Engine::gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e) {
+    if (!e.bias) e.bias = w.b;
+    const double esz = dt == BF16 ? 2.0 : 4.0;
+    if (prof_on_) {
+        double out_b = (double)M * w.N * (e.mode == EPI_STORE ? (e.out_dtype == BF16 ? 2.0 : 4.0) : (e.mode == EPI_RESID ? 8.0 : 4.0));
+        prof_begin(tag, 2.0 * M * (double)w.N * w.K, ((double)M * w.K + (double)w.N * w.K) * esz + out_b);
+    }
+    launch_gemm(s_, dt, A, lda, w.w.as(dt), w.K, M, w.N, w.K, e);
+    if (prof_on_) prof_end();
+}
+
+void* Engine::to_act(const float* src, int64_t n) {
+    if (dt_ == F32) return const_cast<float*>(src);
+    void* d = act_alloc(n);
+    launch_cast(s_, dt_, src, n, d);
+    return d;
+}
+
+// x <- (x + gamma * pw2(GELU(pw1(LN(dwconv(x)))))) * mask      (in place, x fp32 [B*L][C])
+void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len) {
+    const int64_t M = (int64_t)B * L;
+    const Arena::Mark mk = ar_.mark();
+    void* xn = act_alloc(M * C);
+    void* u = act_alloc(M * hid);
+    if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (dt_ == BF16 ? 2.0 : 4.0)));
+    launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn);
+    if (prof_on_) prof_end();
+    Epilogue e1;
+    e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
+    gemm("gemm_pw1_gelu", dt_, xn, C, p.pw1, (int)M, e1);
+    Epilogue e2;
+    e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.gamma = p.gamma; e2.len = len; e2.L = L;
+    gemm("gemm_pw2_resid", dt_, u, hid, p.pw2, (int)M, e2);
+    ar_.release(mk);
+}
+
+// x <- (x + Wo attn(LN(x) Wq, ctx Wk, ctx Wv)) * mask.   self: ctx = LN(x), one fused QKV GEMM.
+void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
+                        const int* klen, int rope_mode, bool self) {
+    const int64_t Mq = (int64_t)B * Lq, Mk = (int64_t)B * Lk;
+    const Arena::Mark mk = ar_.mark();
+    const size_t esz = dt_ == BF16 ? 2 : 4;
+    void* xn = act_alloc(Mq * C);
+    if (prof_on_) prof_begin("layernorm", (double)Mq * C * 8, (double)Mq * C * (4.0 + esz));
+    launch_layernorm(s_, dt_, x, Mq, C, p.ln.g, p.ln.b, a_.ln_eps, xn);
+    if (prof_on_) prof_end();
+    const char *q = nullptr, *k = nullptr, *v = nullptr;
+    int ldq = C, ldk = 2 * C;
+    if (self) {
+        void* qkv = act_alloc(Mq * 3 * C);
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = qkv; e.ldo = 3 * C;
+        gemm("gemm_qkv", dt_, xn, C, p.qkv, (int)Mq, e);
+        q = static_cast<const char*>(qkv); k = q + (size_t)C * esz; v = q + (size_t)2 * C * esz;
+        ldq = ldk = 3 * C;
+    } else {
+        void* qb = act_alloc(Mq * C);
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = qb; e.ldo = C;
+        gemm("gemm_q", dt_, xn, C, p.q, (int)Mq, e);
+        q = static_cast<const char*>(qb);
+        void* kv = act_alloc(Mk * 2 * C);
+        Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = dt_; e2.out = kv; e2.ldo = 2 * C;
+        gemm("gemm_kv", dt_, ctx, p.kv.K, p.kv, (int)Mk, e2);
+        k = static_cast<const char*>(kv);
+        v = k + (size_t)C * esz;
+    }
+    void* o = act_alloc(Mq * C);
+    if (prof_on_) prof_begin("attention", 4.0 * Mq * (double)Lk * C, (double)(Mq * 2 + Mk * 2) * C * esz);
+    launch_attention(s_, dt_, q, ldq, k, v, ldk, o, C, B, Lq, Lk, H, C / H, qlen, klen, rope_mode, a_.rope_base, a_.larope_gamma);
+    if (prof_on_) prof_end();
+    Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = qlen; eo.L = Lq;
+    gemm("gemm_attn_out", dt_, o, C, p.o, (int)Mq, eo);
+    ar_.release(mk);
+}
+
+// =================================================================================================
+// stages (device level)
+// =================================================================================================
+void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur) {
+    const stn_arch& a = a_;
+    const int C = a.dp_dim;
+    const int64_t M = (int64_t)B * Lt;
+    const Arena::Mark mk = ar_.mark();
+    float* x = f32_alloc(M * C);
+    launch_embed(s_, ids, vecf("dp.emb"), a.vocab_size, B, Lt, C, tlen, x);
+    for (int i = 0; i < a.dp_conv_blocks; ++i)
+        convnext(convnext_w("dp.conv" + std::to_string(i)), x, B, Lt, C, a.dp_hidden, a.dp_kernel, 1, tlen);
+    void* st = to_act(style_dp, (int64_t)B * a.n_style_dp * a.d_style_dp);
+    attn_block(attn_w("dp.st", false), x, B, Lt, C, a.dp_heads, st, a.n_style_dp, tlen, nullptr, -1, false);
+    float* xn = f32_alloc(M * C);
+    const LNorm ln = lnorm("dp.out_ln");
+    launch_layernorm(s_, F32, x, M, C, ln.g, ln.b, a.ln_eps, xn);
+    float* pooled = f32_alloc((int64_t)B * C);
+    launch_masked_mean(s_, F32, xn, B, Lt, C, tlen, pooled);
+    float* h = f32_alloc((int64_t)B * C);
+    Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = F32; e1.out = h; e1.ldo = C;
+    gemm("gemm_small_f32", F32, pooled, C, linear("dp.fc1"), B, e1);
+    Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = F32; e2.out = dur; e2.ldo = 1;
+    gemm("gemm_small_f32", F32, h, C, linear("dp.fc2"), B, e2);
+    launch_softplus(s_, dur, B);
+    ar_.release(mk);
+}
+
+void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl,
+                          void* rows) {
+    const stn_arch& a = a_;
+    const int C = a.te_dim, Ce = a.te_out_dim;
+    const int64_t M = (int64_t)B * Lt;
+    const Arena::Mark mk = ar_.mark();
+    float* x = f32_alloc(M * C);
+    launch_embed(s_, ids, vecf("te.emb"), a.vocab_size, B, Lt, C, tlen, x);
+    for (int i = 0; i < a.te_conv_blocks; ++i)
+        convnext(convnext_w("te.conv" + std::to_string(i)), x, B, Lt, C, a.te_hidden, a.te_kernel, 1, tlen);
+    for (int i = 0; i < a.te_attn_blocks; ++i) {
+        const std::string p = "te.sa" + std::to_string(i);
+        attn_block(attn_w(p, true), x, B, Lt, C, a.te_heads, nullptr, Lt, tlen, tlen, 0, true);
+        const Arena::Mark m2 = ar_.mark();
+        void* xn = act_alloc(M * C);
+        void* u = act_alloc(M * a.te_ffn);
+        const LNorm ln = lnorm(p + ".ffn_ln");
+        launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
+        Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = a.te_ffn;
+        gemm("gemm_pw1_gelu", dt_, xn, C, linear(p + ".ffn1"), (int)M, e1);
+        Epilogue e2; e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.len = tlen; e2.L = Lt;
+        gemm("gemm_pw2_resid", dt_, u, a.te_ffn, linear(p + ".ffn2"), (int)M, e2);
+        ar_.release(m2);
+    }
+    void* st = to_act(style_ttl, (int64_t)B * a.n_style_ttl * a.d_style_ttl);
+    for (int i = 0; i < a.te_style_blocks; ++i)
+        attn_block(attn_w("te.st" + std::to_string(i), false), x, B, Lt, C, a.te_heads, st, a.n_style_ttl, tlen, nullptr,
+                   -1, false);
+    void* xn = act_alloc(M * C);
+    const LNorm ln = lnorm("te.out_ln");
+    launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
+    const Linear proj = linear("te.proj");
+    if (ncl) {
+        Epilogue e; e.mode = EPI_STORE_T; e.out = ncl; e.len = tlen; e.L = Lt;
+        gemm("gemm_proj", dt_, xn, C, proj, (int)M, e);
+    }
+    if (rows) {
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = rows; e.ldo = Ce; e.len = tlen; e.L = Lt;
+        gemm("gemm_proj", dt_, xn, C, proj, (int)M, e);
+    }
+    ar_.release(mk);
+}
+
+// K/V of the text and style contexts for every main block: invariant across Euler steps.
+// The returned buffers live in the arena ABOVE the caller's mark: the caller releases them.
+Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl) {
+    const stn_arch& a = a_;
+    const int C = a.ve_dim, nb = a.ve_main_blocks;
+    VeCtx c;
+    c.Lt = Lt;
+    c.text_kv = act_alloc((int64_t)B * Lt * nb * 2 * C);
+    c.style_kv = act_alloc((int64_t)B * a.n_style_ttl * nb * 2 * C);
+    Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = c.text_kv; e.ldo = nb * 2 * C;
+    gemm("gemm_kv", dt_, text_rows, a.te_out_dim, linear("ve.text_kv_all"), B * Lt, e);
+    void* st = to_act(style_ttl, (int64_t)B * a.n_style_ttl * a.d_style_ttl);
+    Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = dt_; e2.out = c.style_kv; e2.ldo = nb * 2 * C;
+    gemm("gemm_kv", dt_, st, a.d_style_ttl, linear("ve.style_kv_all"), B * a.n_style_ttl, e2);
+    return c;
+}
+
+void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
+                         const float* total_step, const float* current_step, float* denoised) {
+    const stn_arch& a = a_;
+    const int C = a.ve_dim, D = a.latent_dim * a.chunk_compress_factor, nb = a.ve_main_blocks, H = a.ve_heads;
+    const int64_t M = (int64_t)B * L;
+    const size_t esz = dt_ == BF16 ? 2 : 4;
+    const Arena::Mark mk = ar_.mark();
+    void* z = act_alloc(M * D);
+    launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z);
+    float* x = f32_alloc(M * C);
+    Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = x; ein.ldo = C; ein.len = llen; ein.L = L;
+    gemm("gemm_in", dt_, z, D, linear("ve.in"), (int)M, ein);
+    // time conditioning (fp32, tiny)
+    float* te = f32_alloc((int64_t)B * a.ve_time_dim);
+    launch_time_embed(s_, current_step, total_step, B, a.ve_time_dim, a.time_scale, te);
+    float* t1 = f32_alloc((int64_t)B * C);
+    Epilogue et1; et1.mode = EPI_STORE; et1.act = ACT_SILU; et1.out_dtype = F32; et1.out = t1; et1.ldo = C;
+    gemm("gemm_small_f32", F32, te, a.ve_time_dim, linear("ve.t1"), B, et1);
+    float* tc = f32_alloc((int64_t)B * C);
+    Epilogue et2; et2.mode = EPI_STORE; et2.out_dtype = F32; et2.out = tc; et2.ldo = C;
+    gemm("gemm_small_f32", F32, t1, C, linear("ve.t2"), B, et2);
+    float* tb = f32_alloc((int64_t)B * nb * C);
+    Epilogue et3; et3.mode = EPI_STORE; et3.out_dtype = F32; et3.out = tb; et3.ldo = nb * C;
+    gemm("gemm_small_f32", F32, tc, C, linear("ve.time_all"), B, et3);
+
+    auto cross = [&](const std::string& p, const void* kv_all, int blk, int Lk, const int* klen, int rope_mode) {
+        // q from x, K/V precomputed (columns blk*2C .. of kv_all, row stride nb*2C)
+        const Attn w = attn_w(p, false);
+        const Arena::Mark m2 = ar_.mark();
+        void* xn = act_alloc(M * C);
+        launch_layernorm(s_, dt_, x, M, C, w.ln.g, w.ln.b, a.ln_eps, xn);
+        void* qb = act_alloc(M * C);
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = qb; e.ldo = C;
+        gemm("gemm_q", dt_, xn, C, w.q, (int)M, e);
+        const char* kp = static_cast<const char*>(kv_all) + (size_t)blk * 2 * C * esz;
+        const char* vp = kp + (size_t)C * esz;
+        void* o = act_alloc(M * C);
+        if (prof_on_) prof_begin("attention", 4.0 * M * (double)Lk * C, (double)(M * 2 + (int64_t)B * Lk * 2) * C * esz);
+        launch_attention(s_, dt_, qb, C, kp, vp, nb * 2 * C, o, C, B, L, Lk, H, C / H, llen, klen, rope_mode, a.rope_base,
+                         a.larope_gamma);
+        if (prof_on_) prof_end();
+        Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = llen; eo.L = L;
+        gemm("gemm_attn_out", dt_, o, C, w.o, (int)M, eo);
+        ar_.release(m2);
+    };
+
+    for (int blk = 0; blk < nb; ++blk) {
+        const std::string p = "ve.m" + std::to_string(blk);
+        for (int j = 0; j < a.ve_dilated; ++j)
+            convnext(convnext_w(p + ".dil" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1 << j, llen);
+        launch_add_rowvec(s_, x, tb + (size_t)blk * C, nb * C, B, L, C, llen);
+        convnext(convnext_w(p + ".cn_a"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
+        cross(p + ".text", c.text_kv, blk, c.Lt, tlen, 1);
+        convnext(convnext_w(p + ".cn_b"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
+        cross(p + ".style", c.style_kv, blk, a.n_style_ttl, nullptr, -1);
+    }
+    for (int j = 0; j < a.ve_tail_blocks; ++j)
+        convnext(convnext_w("ve.tail" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
+    void* xn = act_alloc(M * C);
+    const LNorm ln = lnorm("ve.out_ln");
+    launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
+    // Euler update fused into the output projection; dt[b] = 1 / total_step[b]
+    float* dtv = f32_alloc(B);
+    launch_reciprocal(s_, total_step, B, dtv);
+    Epilogue eo; eo.mode = EPI_EULER_T; eo.out = denoised; eo.aux = noisy; eo.row_scale = dtv; eo.len = llen; eo.L = L;
+    gemm("gemm_out_euler", dt_, xn, C, linear("ve.out"), (int)M, eo);
+    ar_.release(mk);
+}
+
+void Engine::vocoder_dev(int B, int L, const float* latent, float* wav) {
+    const stn_arch& a = a_;
+    const int C = a.vo_dim, T = L * a.chunk_compress_factor;
+    const int64_t M = (int64_t)B * T;
+    const Arena::Mark mk = ar_.mark();
+    float* x = f32_alloc(M * C);
+    if (prof_on_) prof_begin("vocoder_in", 2.0 * M * C * a.latent_dim * a.vo_in_kernel, (double)M * (a.latent_dim + C) * 4.0);
+    launch_vocoder_in(s_, latent, B, L, a.latent_dim, a.chunk_compress_factor, vecf("vo.in.wt"), vecf("vo.in.b"), C,
+                      a.vo_in_kernel, x);
+    if (prof_on_) prof_end();
+    for (int i = 0; i < a.vo_blocks; ++i)
+        convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i], nullptr);
+    void* xn = act_alloc(M * C);
+    const LNorm ln = lnorm("vo.out_ln");
+    launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
+    // head: transposed conv with kernel = stride = base_chunk_size == per-frame linear; rows of the GEMM output ARE the wave
+    Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wav; e.ldo = a.base_chunk_size;
+    gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
+    ar_.release(mk);
+}
+
+// =================================================================================================
+// host-pointer stages (the four former Run sites)
+// =================================================================================================
+namespace {
+template <typename T>
+T* up(Arena& ar, hipStream_t s, const T* h, size_t n) {
+    T* d = static_cast<T*>(ar.alloc(n * sizeof(T)));
+    STN_HIP(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return d;
+}
+}  // namespace
+
+void Engine::duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    int64_t* d_ids = up(ar_, s_, ids, (size_t)B * Lt);
+    float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt);
+    float* d_st = up(ar_, s_, style_dp, (size_t)B * a_.n_style_dp * a_.d_style_dp);
+    int* tlen = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+    float* d_dur = f32_alloc(B);
+    launch_mask_to_len(s_, d_mask, B, Lt, tlen);
+    duration_dev(B, Lt, d_ids, d_st, tlen, d_dur);
+    STN_HIP(hipMemcpyAsync(dur, d_dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::text_enc(int B, int Lt, const int64_t* ids, const float* style_ttl, const float* text_mask, float* text_emb) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    int64_t* d_ids = up(ar_, s_, ids, (size_t)B * Lt);
+    float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt);
+    float* d_st = up(ar_, s_, style_ttl, (size_t)B * a_.n_style_ttl * a_.d_style_ttl);
+    int* tlen = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+    const size_t n = (size_t)B * a_.te_out_dim * Lt;
+    float* d_out = f32_alloc(n);
+    launch_mask_to_len(s_, d_mask, B, Lt, tlen);
+    text_enc_dev(B, Lt, d_ids, d_st, tlen, d_out, nullptr);
+    STN_HIP(hipMemcpyAsync(text_emb, d_out, n * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::vector_est(int B, int L, int Lt, const float* noisy, const float* text_emb, const float* style_ttl,
+                        const float* text_mask, const float* latent_mask, const float* total_step,
+                        const float* current_step, float* denoised) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    const int D = a_.latent_dim * a_.chunk_compress_factor, Ce = a_.te_out_dim;
+    float* d_x = up(ar_, s_, noisy, (size_t)B * D * L);
+    float* d_emb = up(ar_, s_, text_emb, (size_t)B * Ce * Lt);
+    float* d_st = up(ar_, s_, style_ttl, (size_t)B * a_.n_style_ttl * a_.d_style_ttl);
+    float* d_tm = up(ar_, s_, text_mask, (size_t)B * Lt);
+    float* d_lm = up(ar_, s_, latent_mask, (size_t)B * L);
+    float* d_tot = up(ar_, s_, total_step, (size_t)B);
+    float* d_cur = up(ar_, s_, current_step, (size_t)B);
+    int* tlen = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+    int* llen = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+    float* d_out = f32_alloc((size_t)B * D * L);
+    launch_mask_to_len(s_, d_tm, B, Lt, tlen);
+    launch_mask_to_len(s_, d_lm, B, L, llen);
+    void* rows = act_alloc((int64_t)B * Lt * Ce);
+    launch_ncl_to_rows(s_, dt_, d_emb, B, Ce, Lt, rows);
+    VeCtx c = ve_prepare_dev(B, Lt, rows, d_st);
+    ve_step_dev(B, L, c, d_x, tlen, llen, d_tot, d_cur, d_out);
+    STN_HIP(hipMemcpyAsync(denoised, d_out, (size_t)B * D * L * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::vocoder(int B, int L, const float* latent, float* wav) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    const int D = a_.latent_dim * a_.chunk_compress_factor;
+    const size_t nw = (size_t)B * L * a_.base_chunk_size * a_.chunk_compress_factor;
+    float* d_lat = up(ar_, s_, latent, (size_t)B * D * L);
+    float* d_wav = f32_alloc(nw);
+    vocoder_dev(B, L, d_lat, d_wav);
+    STN_HIP(hipMemcpyAsync(wav, d_wav, nw * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+// =================================================================================================
+// resident batch
+// =================================================================================================
+namespace {
+template <typename T>
+void grow(std::vector<void*>& owned, T*& p, size_t& cap, size_t need) {
+    if (need <= cap && p) return;
+    T* n = nullptr;
+    STN_HIP(hipMalloc(reinterpret_cast<void**>(&n), std::max<size_t>(need, 64) * sizeof(T)));
+    owned.push_back(n);  // the old buffer stays owned until the next upload (no free while work may be in flight)
+    p = n;
+    cap = need;
+}
+template <typename T>
+T* dmalloc(std::vector<void*>& owned, size_t n) {
+    T* p = nullptr;
+    STN_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 64) * sizeof(T)));
+    owned.push_back(p);
+    return p;
+}
+}  // namespace
+
+void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_mask, const float* style_ttl,
+                          const float* style_dp, const float* duration_override, const int64_t* utt_ids) {
+    STN_HIP(hipSetDevice(device_));
+    if (!loaded_) throw std::runtime_error("no model loaded");
+    if (B <= 0 || Lt <= 0) throw std::runtime_error("empty batch");
+    sync();
+    for (void* p : batch_owned_) (void)hipFree(p);
+    batch_owned_.clear();
+    bt_ = Batch{};
+    Batch& b = bt_;
+    b.B = B; b.Lt = Lt;
+    const size_t n_ttl = (size_t)B * a_.n_style_ttl * a_.d_style_ttl, n_dp = (size_t)B * a_.n_style_dp * a_.d_style_dp;
+    b.ids = dmalloc<int64_t>(batch_owned_, (size_t)B * Lt);
+    b.tlen = dmalloc<int>(batch_owned_, B);
+    b.style_ttl = dmalloc<float>(batch_owned_, n_ttl);
+    b.style_dp = dmalloc<float>(batch_owned_, n_dp);
+    b.dur = dmalloc<float>(batch_owned_, B);
+    b.llen = dmalloc<int>(batch_owned_, B);
+    b.utt_ids = dmalloc<int64_t>(batch_owned_, B);
+    b.steps = dmalloc<float>(batch_owned_, (size_t)2 * B);
+    STN_HIP(hipMemcpyAsync(b.ids, ids, sizeof(int64_t) * B * Lt, hipMemcpyHostToDevice, s_));
+    STN_HIP(hipMemcpyAsync(b.style_ttl, style_ttl, sizeof(float) * n_ttl, hipMemcpyHostToDevice, s_));
+    STN_HIP(hipMemcpyAsync(b.style_dp, style_dp, sizeof(float) * n_dp, hipMemcpyHostToDevice, s_));
+    std::vector<int64_t> uid(B);
+    for (int i = 0; i < B; ++i) uid[i] = utt_ids ? utt_ids[i] : i;
+    STN_HIP(hipMemcpyAsync(b.utt_ids, uid.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s_));
+    ar_.reset();
+    float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt);
+    launch_mask_to_len(s_, d_mask, B, Lt, b.tlen);
+    b.have_override = duration_override != nullptr;
+    if (duration_override) b.h_dur.assign(duration_override, duration_override + B);
+    sync();
+}
+
+void Engine::batch_set_noise(const float* noise, int L) {
+    STN_HIP(hipSetDevice(device_));
+    Batch& b = bt_;
+    if (b.B == 0) throw std::runtime_error("batch_set_noise: no batch uploaded");
+    if (L < 1) throw std::runtime_error("batch_set_noise: L must be >= 1");
+    const int D = a_.latent_dim * a_.chunk_compress_factor;
+    sync();
+    grow(batch_owned_, b.noise, b.noise_cap, (size_t)b.B * D * L);
+    STN_HIP(hipMemcpyAsync(b.noise, noise, sizeof(float) * b.B * D * L, hipMemcpyHostToDevice, s_));
+    b.have_noise = true;
+    b.noise_L = L;  // checked against the durations in batch_run
+    sync();
+}
+
+// Latent geometry exactly as TextToSpeech::sampleNoisyLatent (/root/reference/cpp/helper.cpp:424-440,457,764-768):
+// float32 products, truncation to integers.
+static void latent_geometry(const stn_arch& a, const std::vector<float>& dur, int& L, std::vector<int>& llen) {
+    const int cs = a.base_chunk_size * a.chunk_compress_factor;
+    float mx = dur[0];
+    for (float d : dur) mx = std::max(mx, d);
+    const float wav_len_max = mx * (float)a.sample_rate;
+    L = (int)((wav_len_max + (float)cs - 1.0f) / (float)cs);
+    llen.resize(dur.size());
+    for (size_t i = 0; i < dur.size(); ++i) {
+        const int64_t wl = (int64_t)(dur[i] * (float)a.sample_rate);
+        llen[i] = (int)((wl + cs - 1) / cs);
+    }
+}
+
+void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
+    STN_HIP(hipSetDevice(device_));
+    Batch& b = bt_;
+    if (b.B == 0) throw std::runtime_error("batch_run: no batch uploaded");
+    if (total_step < 1) throw std::runtime_error("total_step must be >= 1");
+    if (!(speed > 0.f)) throw std::runtime_error("speed must be > 0");
+    const stn_arch& a = a_;
+    const int B = b.B, Lt = b.Lt, D = a.latent_dim * a.chunk_compress_factor;
+    b.total_step = total_step; b.speed = speed; b.noise_seed = noise_seed;
+    ar_.reset();
+    // 1. duration predictor (always executed; its output may be overridden for shape control)
+    duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur);
+    std::vector<float> dur(B);
+    if (b.have_override) {
+        dur = b.h_dur;  // known on the host: no device->host read, no sync
+    } else {
+        STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
+        sync();  // the one host round trip: L = f(max duration) sizes every later buffer
+    }
+    for (float& d : dur) d /= speed;  // cpp/helper.cpp:529-531
+    int L = 0;
+    latent_geometry(a, dur, L, b.h_llen);
+    if (L < 1) throw std::runtime_error("predicted duration too short: zero latent frames");
+    if (b.have_noise && b.noise_L != L)
+        throw std::runtime_error("injected noise has L=" + std::to_string(b.noise_L) + " but the durations imply L=" + std::to_string(L));
+    b.L = L;
+    STN_HIP(hipMemcpyAsync(b.llen, b.h_llen.data(), sizeof(int) * B, hipMemcpyHostToDevice, s_));
+    reported_dur_ = dur;  // durations after /speed: what the reference returns (cpp/helper.cpp:680)
+    const size_t nx = (size_t)B * D * L, nw = (size_t)B * L * a.base_chunk_size * a.chunk_compress_factor;
+    if (nx > b.xt_cap) {
+        size_t c0 = 0, c1 = 0;
+        b.xt[0] = nullptr; b.xt[1] = nullptr;
+        grow(batch_owned_, b.xt[0], c0, nx);
+        grow(batch_owned_, b.xt[1], c1, nx);
+        b.xt_cap = nx;
+    }
+    grow(batch_owned_, b.wav, b.wav_cap, nw);
+    // 2. text encoder -> context rows (act dtype)
+    void* text_rows = act_alloc((int64_t)B * Lt * a.te_out_dim);
+    text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, text_rows);
+    // 3. initial latent
+    if (b.have_noise) {
+        STN_HIP(hipMemcpyAsync(b.xt[0], b.noise, nx * 4, hipMemcpyDeviceToDevice, s_));
+        launch_mask_ncl(s_, b.xt[0], B, D, L, b.llen);
+    } else {
+        launch_randn_masked(s_, noise_seed, b.utt_ids, B, D, L, b.llen, b.xt[0]);
+    }
+    // 4. Euler loop: step-invariant K/V once, then total_step estimator passes
+    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl);
+    launch_fill(s_, b.steps, B, (float)total_step);
+    int cur = 0;
+    for (int st = 0; st < total_step; ++st) {
+        launch_fill(s_, b.steps + B, B, (float)st);
+        ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, b.steps, b.steps + B, b.xt[cur ^ 1]);
+        cur ^= 1;
+    }
+    final_xt_ = cur;
+    // 5. vocoder
+    vocoder_dev(B, L, b.xt[cur], b.wav);
+}
+
+void Engine::batch_fetch(float* wav, size_t wav_capacity, float* duration) {
+    Batch& b = bt_;
+    const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
+    if (wav) {
+        if (wav_capacity < nw) throw std::runtime_error("wav buffer too small: need " + std::to_string(nw) + " floats");
+        STN_HIP(hipMemcpyAsync(wav, b.wav, nw * 4, hipMemcpyDeviceToHost, s_));
+    }
+    sync();
+    if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
+}
+void Engine::batch_fetch_latent(float* latent) {
+    Batch& b = bt_;
+    const size_t nx = (size_t)b.B * a_.latent_dim * a_.chunk_compress_factor * b.L;
+    STN_HIP(hipMemcpyAsync(latent, b.xt[final_xt_], nx * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+// =================================================================================================
+// op-level test entry points
+// =================================================================================================
+void Engine::op_gemm(int dtype, int M, int N, int K, const float* A, const float* W, const float* bias, int act, float* out) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    float* dA = up(ar_, s_, A, (size_t)M * K);
+    float* dW = up(ar_, s_, W, (size_t)N * K);
+    float* dB = bias ? up(ar_, s_, bias, (size_t)N) : nullptr;
+    float* dO = f32_alloc((size_t)M * N);
+    const void* pa = dA;
+    const void* pw = dW;
+    if (dtype == BF16) {
+        void* a16 = ar_.alloc((size_t)M * K * 2);
+        void* w16 = ar_.alloc((size_t)N * K * 2);
+        launch_cast(s_, BF16, dA, (int64_t)M * K, a16);
+        launch_cast(s_, BF16, dW, (int64_t)N * K, w16);
+        pa = a16; pw = w16;
+    }
+    Epilogue e; e.mode = EPI_STORE; e.act = act; e.out_dtype = F32; e.out = dO; e.ldo = N; e.bias = dB;
+    launch_gemm(s_, dtype, pa, K, pw, K, M, N, K, e);
+    STN_HIP(hipMemcpyAsync(out, dO, (size_t)M * N * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w, const float* bias,
+                          const float* g, const float* b, float* y) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    const size_t n = (size_t)B * L * C;
+    std::vector<float> wt((size_t)C * k);
+    for (int c = 0; c < C; ++c) for (int j = 0; j < k; ++j) wt[(size_t)j * C + c] = w[(size_t)c * k + j];
+    float* dx = up(ar_, s_, x, n);
+    float* dw = up(ar_, s_, wt.data(), wt.size());
+    float* db = up(ar_, s_, bias, (size_t)C);
+    float* dg = up(ar_, s_, g, (size_t)C);
+    float* dbt = up(ar_, s_, b, (size_t)C);
+    void* dy = ar_.alloc(n * 4);
+    float* dy32 = f32_alloc(n);
+    launch_dwconv_ln(s_, dtype, dx, B, L, C, dw, db, k, dil, dg, dbt, 1e-6f, dy);
+    if (dtype == BF16) launch_bf16_to_f32(s_, static_cast<const uint16_t*>(dy), (int64_t)n, dy32);
+    STN_HIP(hipMemcpyAsync(y, dtype == BF16 ? dy32 : static_cast<float*>(dy), n * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k, const float* v,
+                          const int* qlen, const int* klen, int rope_mode, float* o) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    const int C = H * dh;
+    const size_t nq = (size_t)B * Lq * C, nk = (size_t)B * Lk * C;
+    float* dq = up(ar_, s_, q, nq);
+    float* dk = up(ar_, s_, k, nk);
+    float* dv = up(ar_, s_, v, nk);
+    int* dql = qlen ? up(ar_, s_, qlen, (size_t)B) : nullptr;
+    int* dkl = klen ? up(ar_, s_, klen, (size_t)B) : nullptr;
+    const void *pq = dq, *pk = dk, *pv = dv;
+    if (dtype == BF16) {
+        void* a = ar_.alloc(nq * 2); void* b = ar_.alloc(nk * 2); void* c = ar_.alloc(nk * 2);
+        launch_cast(s_, BF16, dq, (int64_t)nq, a); launch_cast(s_, BF16, dk, (int64_t)nk, b); launch_cast(s_, BF16, dv, (int64_t)nk, c);
+        pq = a; pk = b; pv = c;
+    }
+    void* dO = ar_.alloc(nq * 4);
+    float* dO32 = f32_alloc(nq);
+    launch_attention(s_, dtype, pq, C, pk, pv, C, dO, C, B, Lq, Lk, H, dh, dql, dkl, rope_mode, a_.rope_base > 0 ? a_.rope_base : 10000.f,
+                     a_.larope_gamma > 0 ? a_.larope_gamma : 10.f);
+    if (dtype == BF16) launch_bf16_to_f32(s_, static_cast<const uint16_t*>(dO), (int64_t)nq, dO32);
+    STN_HIP(hipMemcpyAsync(o, dtype == BF16 ? dO32 : static_cast<float*>(dO), nq * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    int64_t* du = utt_ids ? up(ar_, s_, utt_ids, (size_t)B) : nullptr;
+    int* dl = len ? up(ar_, s_, len, (size_t)B) : nullptr;
+    float* d = f32_alloc((size_t)B * D * L);
+    launch_randn_masked(s_, seed, du, B, D, L, dl, d);
+    STN_HIP(hipMemcpyAsync(out, d, (size_t)B * D * L * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+}  // namespace stn

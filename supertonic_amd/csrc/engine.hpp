@@ -1,0 +1,172 @@
+// engine.hpp — MI355X-native executor of the four Supertonic graphs.
+//
+// Replaces what the reference does with four `Ort::Session`s (/root/reference/cpp/helper.cpp:776-795) and
+// their `Run` calls (:519, :552, :643, :668).  One Engine = one GPU + one HIP stream; all stages are
+// enqueued on that stream with no host round trip except the single read of the predicted durations that
+// sizes the latent (cpp/helper.cpp:430-438 needs max(duration) on the host too).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/stn_arch.h"
+#include "kernels.hpp"
+
+namespace stn {
+
+#define STN_HIP(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);       \
+    } while (0)
+
+struct DevTensor {
+    float* f32 = nullptr;      // canonical fp32 copy (layout noted per tensor)
+    uint16_t* bf16 = nullptr;  // bf16 copy for GEMM operands (matrices only)
+    int rows = 0, cols = 0;
+    const void* as(int dt) const { return dt == BF16 ? static_cast<const void*>(bf16) : static_cast<const void*>(f32); }
+};
+
+struct Linear { DevTensor w; const float* b = nullptr; int N = 0, K = 0; };
+struct LNorm { const float* g = nullptr; const float* b = nullptr; };
+struct ConvNeXt { const float* dw_t = nullptr; const float* dw_b = nullptr; LNorm ln; Linear pw1, pw2; const float* gamma = nullptr; };
+struct Attn { LNorm ln; Linear q, kv, qkv, o; };  // kv = [Wk; Wv] rows, qkv = [Wq; Wk; Wv] rows
+
+// Grow-only chunked device workspace.  Stage code takes mark()/release() pairs; all work is stream-ordered,
+// chunks are never freed before the Engine dies, so pointers handed out stay valid while kernels run.
+// New chunks are hipMalloc'ed only the first time a shape needs them (warm-up), never afterwards.
+class Arena {
+   public:
+    struct Mark { size_t chunk, off; };
+    ~Arena();
+    void* alloc(size_t bytes);
+    Mark mark() const { return {cur_, off_}; }
+    void release(Mark m) { cur_ = m.chunk; off_ = m.off; }
+    void reset() { cur_ = 0; off_ = 0; }
+    size_t capacity() const;
+
+   private:
+    struct Chunk { char* p; size_t cap; };
+    std::vector<Chunk> chunks_;
+    size_t cur_ = 0, off_ = 0;
+};
+
+struct KernelStat { double ms = 0; long launches = 0; double flops = 0; double bytes = 0; };
+
+class Engine {
+   public:
+    Engine(int device, int dtype);
+    ~Engine();
+    Engine(const Engine&) = delete;
+
+    void load_synthetic(const stn_arch& a, uint64_t seed);
+    bool loaded() const { return loaded_; }
+    const stn_arch& arch() const { return a_; }
+    int64_t param_count() const { return params_; }
+    int dtype() const { return dt_; }
+    hipStream_t stream() const { return s_; }
+    void sync() { STN_HIP(hipStreamSynchronize(s_)); }
+
+    // ---- device-level stages (all pointers device, enqueued on stream()) -------------------------
+    // lengths are int32 [B] on device.
+    void duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur);
+    // emits text_emb as NCL fp32 [B,Ce,Lt] (if ncl) and/or as rows [B*Lt][Ce] in the act dtype (if rows)
+    void text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl, void* rows);
+    struct VeCtx { void* text_kv = nullptr; void* style_kv = nullptr; int Lt = 0; };  // step-invariant K/V
+    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl);
+    void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
+                     const float* total_step, const float* current_step, float* denoised);
+    void vocoder_dev(int B, int L, const float* latent, float* wav);
+
+    // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
+    void duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur);
+    void text_enc(int B, int Lt, const int64_t* ids, const float* style_ttl, const float* text_mask, float* text_emb);
+    void vector_est(int B, int L, int Lt, const float* noisy, const float* text_emb, const float* style_ttl,
+                    const float* text_mask, const float* latent_mask, const float* total_step,
+                    const float* current_step, float* denoised);
+    void vocoder(int B, int L, const float* latent, float* wav);
+
+    // ---- resident batch: upload once, run on device, fetch --------------------------------------------
+    struct Batch {
+        int B = 0, Lt = 0, L = 0, noise_L = 0, total_step = 0;
+        float speed = 1.f;
+        bool have_override = false, have_noise = false;
+        uint64_t noise_seed = 0;
+        int64_t* ids = nullptr; int* tlen = nullptr; float* style_ttl = nullptr; float* style_dp = nullptr;
+        float* dur = nullptr; int* llen = nullptr; int64_t* utt_ids = nullptr;
+        float* noise = nullptr; size_t noise_cap = 0;   // injected noise [B,D,L] (optional)
+        float* xt[2] = {nullptr, nullptr}; size_t xt_cap = 0;
+        float* wav = nullptr; size_t wav_cap = 0;        // [B, L*cs]
+        float* steps = nullptr;                          // [2][B]: total_step, current_step
+        std::vector<float> h_dur; std::vector<int> h_llen;
+    };
+    void batch_upload(int B, int Lt, const int64_t* ids, const float* text_mask, const float* style_ttl,
+                      const float* style_dp, const float* duration_override, const int64_t* utt_ids);
+    void batch_set_noise(const float* noise, int L);  // injected xt for the L the durations imply
+    void batch_run(int total_step, float speed, uint64_t noise_seed);
+    const Batch& batch() const { return bt_; }
+    void batch_fetch(float* wav, size_t wav_capacity, float* duration);
+    void batch_fetch_latent(float* latent);  // final denoised latent [B,D,L] (tests)
+
+    // ---- profiling (hipEvent pairs around launches of one kernel family, on this stream) ----------------
+    void profile_enable(bool on) { prof_on_ = on; }
+    void profile_reset();
+    std::vector<std::pair<std::string, KernelStat>> profile_collect();
+
+    // ---- op-level test entry points (host pointers) ------------------------------------------------------
+    void op_gemm(int dtype, int M, int N, int K, const float* A, const float* W, const float* bias, int act, float* out);
+    void op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k, const float* v,
+                      const int* qlen, const int* klen, int rope_mode, float* o);
+    void op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w, const float* bias,
+                      const float* g, const float* b, float* y);
+    void op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out);
+
+    Arena& arena() { return ar_; }
+
+   private:
+    // weights
+    DevTensor& tensor(const std::string& name);
+    const float* vecf(const std::string& name) { return tensor(name).f32; }
+    Linear linear(const std::string& prefix);
+    LNorm lnorm(const std::string& prefix);
+    ConvNeXt convnext_w(const std::string& prefix);
+    Attn attn_w(const std::string& prefix, bool self);
+    void free_weights();
+
+    // building blocks (enqueue on s_)
+    size_t act_bytes(int64_t n) const { return (size_t)n * (dt_ == BF16 ? 2 : 4); }
+    void* act_alloc(int64_t n) { return ar_.alloc(act_bytes(n)); }
+    float* f32_alloc(int64_t n) { return static_cast<float*>(ar_.alloc((size_t)n * 4)); }
+    void gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e);
+    void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len);
+    void attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
+                    const int* klen, int rope_mode, bool self);
+    void* to_act(const float* src, int64_t n);
+
+    struct ProfSpan { std::string tag; hipEvent_t a, b; double flops, bytes; };
+    void prof_begin(const char* tag, double flops, double bytes);
+    void prof_end();
+
+    int device_, dt_;
+    hipStream_t s_ = nullptr;
+    stn_arch a_{};
+    bool loaded_ = false;
+    int64_t params_ = 0;
+    std::unordered_map<std::string, DevTensor> w_;
+    std::vector<void*> owned_;
+    Arena ar_;
+    Batch bt_;
+    std::vector<void*> batch_owned_;
+    std::vector<float> reported_dur_;
+    int final_xt_ = 0;
+    bool prof_on_ = false;
+    std::vector<ProfSpan> spans_;
+    std::vector<hipEvent_t> ev_pool_;
+};
+
+}  // namespace stn

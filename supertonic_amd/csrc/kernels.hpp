@@ -1,0 +1,92 @@
+// kernels.hpp — launch interface of the hand-written gfx950 kernels (kernels_*.hip).
+// Activation layout everywhere: row-major [rows = b*len + t][channels].
+// The residual stream is always fp32; "operand" activations (LayerNorm outputs, GELU hidden,
+// q/k/v/o) are `act_t` = float (STN_F32) or bf16 (STN_BF16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stn {
+
+enum DType : int { F32 = 0, BF16 = 1 };
+enum ActFn : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
+// GEMM epilogue description:  acc[m][n] = sum_k A[m][k] * W[n][k]
+enum EpiMode : int {
+    EPI_STORE = 0,    // out[m*ldo + n] = act(acc + bias[n]) * rowmask(m)        (out dtype = out_dtype)
+    EPI_RESID = 1,    // resid[m*ldo+n] = (resid + gamma[n]*(acc+bias[n])) * rowmask(m)      (fp32, in place)
+    EPI_EULER_T = 2,  // out[b][n][t] = (aux[b][n][t] + (acc+bias[n]) * row_scale[b]) * rowmask   (fp32, [B,N,L])
+    EPI_STORE_T = 3,  // out[b][n][t] = (acc+bias[n]) * rowmask                                  (fp32, [B,N,L])
+};
+
+struct Epilogue {
+    int mode = EPI_STORE;
+    int act = ACT_NONE;
+    int out_dtype = F32;         // EPI_STORE only
+    const float* bias = nullptr; // [N] or null
+    void* out = nullptr;         // EPI_STORE / *_T destination
+    int ldo = 0;                 // row stride of out / resid (elements)
+    const float* gamma = nullptr;// [N] layer-scale (EPI_RESID) or null
+    float* resid = nullptr;      // EPI_RESID
+    const int* len = nullptr;    // [B] valid rows per sequence (null -> no row mask)
+    int L = 1;                   // rows per sequence (row m -> b = m / L, t = m % L)
+    const float* aux = nullptr;  // EPI_EULER_T: previous latent [B,N,L]
+    const float* row_scale = nullptr; // EPI_EULER_T: per-b scale (dt)
+};
+
+// A: [M][lda] (dtype), W: [N][ldw] (same dtype), K % 8 == 0 (bf16) / K % 4 == 0 (f32), 16-byte aligned rows.
+void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                 const Epilogue& e);
+
+// depthwise 'same' conv (taps k, dilation dil, weights TRANSPOSED [k][C]) fused with LayerNorm over C.
+// x fp32 [B*L][C] -> y act [B*L][C].  C % 4 == 0, C <= 1024.
+void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L, int C, const float* w_t,
+                      const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y);
+// plain LayerNorm over C: x fp32 -> y act
+void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
+                      float eps, void* y);
+
+// fused attention core: softmax(rope(q) rope(k)^T / sqrt(dh)) v, per (b, head).
+// q [B*Lq][ldq], k/v [B*Lk][ldk] (act dtype); o [B*Lq][ldo] (act dtype).
+// rope_mode: -1 none, 0 position index, 1 length-aware (gamma * t / len).
+void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
+                      int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
+                      float rope_base, float rope_gamma);
+
+// embedding gather: x[b*L+t][:] = (t < len[b] && 0 <= id < vocab) ? emb[id][:] : 0     (fp32 out)
+void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab, int B, int L, int C, const int* len,
+                  float* x);
+// prefix mask [B][L] (float) -> len[B] (count of entries > 0.5)
+void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len);
+// [B][C][L] fp32 -> rows [B*L][C] act
+void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out);
+// fp32 -> act dtype copy (n elements)
+void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out);
+// x[b*L+t][c] += v[b*ldv + c] for t < len[b]
+void launch_add_rowvec(hipStream_t s, float* x, const float* v, int ldv, int B, int L, int C, const int* len);
+// time embedding: te[b][:] = [sin(t*f_i), cos(t*f_i)], t = cur[b]/tot[b]*scale
+void launch_time_embed(hipStream_t s, const float* cur, const float* tot, int B, int dim, float scale, float* te);
+// vocoder front: un-compress [B,D,L] -> frames [B*T][ld] and conv1d ld->C (kernel k, 'same'), fp32 out
+void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld, int ccf, const float* w /*[C][ld][k]*/,
+                       const float* bias, int C, int k, float* x);
+// masked mean over valid rows: pooled[b][c] = sum_{t<len[b]} x[b*L+t][c] / max(len[b],1)   (x act dtype, out fp32)
+void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled);
+// y = softplus(x) elementwise (n small)
+void launch_softplus(hipStream_t s, float* x, int n);
+// durations: d[b] = (override ? override[b] : d[b]) / speed ; computes per-b latent length; see engine
+void launch_scale(hipStream_t s, float* x, int n, float mul);
+// Philox4x32-10 + Box-Muller noise, masked: xt[b][d][t] = t < len[b] ? N(0,1) : 0
+void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, int B, int D, int L, const int* len,
+                         float* xt);
+// xt[b][d][t] *= (t < len[b])
+void launch_mask_ncl(hipStream_t s, float* x, int B, int D, int L, const int* len);
+// out[i] = 1 / in[i]
+void launch_reciprocal(hipStream_t s, const float* in, int n, float* out);
+// bf16 -> fp32 copy (tests)
+void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out);
+// total_step/current_step helper: fill n floats
+void launch_fill(hipStream_t s, float* x, int n, float v);
+// waveform epilogue: pcm[i] = int16(clamp(w[i], -1, 1) * 32767)  (truncation, cpp/helper.cpp:986-987)
+void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t n, int16_t* pcm);
+
+}  // namespace stn

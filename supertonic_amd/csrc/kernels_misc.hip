@@ -1,0 +1,419 @@
+// kernels_misc.hip — the HBM-bound kernels around the GEMMs (gfx950, wave64).
+//
+//   dwconv_ln     depthwise dilated conv along time fused with LayerNorm over channels: one wavefront per
+//                 frame, 16-B (float4) coalesced channel loads, mean/variance by wavefront shuffles; the
+//                 k taps re-read neighbouring frames through L1/L2, HBM sees each frame once.
+//   layernorm     same reduction without the conv.
+//   vocoder_in    latent un-compress + the ld->C input conv of the vocoder, frame window staged in LDS.
+//   + gather / mask / transpose / noise / pcm helpers.
+// All row-major [rows][channels]; see kernels.hpp for the contracts.
+#include "kernels.hpp"
+
+#include <hip/hip_bf16.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace stn {
+
+__device__ __forceinline__ uint16_t f2bf_(float f) {
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<uint16_t*>(&h);
+}
+__device__ __forceinline__ float bf2f_(uint16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(uint16_t* p, float a, float b, float c, float d) {
+    uint2 u;
+    u.x = (unsigned)f2bf_(a) | ((unsigned)f2bf_(b) << 16);
+    u.y = (unsigned)f2bf_(c) | ((unsigned)f2bf_(d) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void store1(float* p, float a) { *p = a; }
+__device__ __forceinline__ void store1(uint16_t* p, float a) { *p = f2bf_(a); }
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const uint16_t* p) { return bf2f_(*p); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise conv + LayerNorm  (CONV=false: LayerNorm only).  One wavefront per frame.
+// ---------------------------------------------------------------------------------------------
+static constexpr int LN_NI = 4;  // float4 slots per lane -> C <= 4 * 64 * LN_NI = 1024
+
+template <typename OutT, bool CONV>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, int64_t M, int L, int C,
+                                                        const float* __restrict__ w_t, const float* __restrict__ bias,
+                                                        int k, int dil, const float* __restrict__ g,
+                                                        const float* __restrict__ bt, float eps, OutT* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;  // wave-uniform
+    const int C4 = C >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4 h[LN_NI];
+    if (CONV) {
+        const int t = (int)(row % L);
+        const int64_t base = row - t;
+        const int half = (k - 1) >> 1;
+        const float4* w4 = reinterpret_cast<const float4*>(w_t);
+        const float4* b4 = reinterpret_cast<const float4*>(bias);
+#pragma unroll
+        for (int i = 0; i < LN_NI; ++i) {
+            const int c4 = lane + 64 * i;
+            h[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 < C4) {
+                float4 a = b4[c4];
+                for (int j = 0; j < k; ++j) {
+                    const int tt = t + (j - half) * dil;
+                    if (tt >= 0 && tt < L) {
+                        const float4 xv = x4[(base + tt) * C4 + c4];
+                        const float4 wv = w4[(int64_t)j * C4 + c4];
+                        a.x = fmaf(wv.x, xv.x, a.x); a.y = fmaf(wv.y, xv.y, a.y);
+                        a.z = fmaf(wv.z, xv.z, a.z); a.w = fmaf(wv.w, xv.w, a.w);
+                    }
+                }
+                h[i] = a;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LN_NI; ++i) {
+            const int c4 = lane + 64 * i;
+            h[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 < C4) h[i] = x4[row * C4 + c4];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i) s += (h[i].x + h[i].y) + (h[i].z + h[i].w);  // slots past C4 hold zeros
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i) {
+        if (lane + 64 * i < C4) {
+            const float dx = h[i].x - mean, dy = h[i].y - mean, dz = h[i].z - mean, dw = h[i].w - mean;
+            v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* bt4 = reinterpret_cast<const float4*>(bt);
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < C4) {
+            const float4 gg = g4[c4], bb = bt4[c4];
+            store4(y + row * C + c4 * 4, (h[i].x - mean) * rstd * gg.x + bb.x, (h[i].y - mean) * rstd * gg.y + bb.y,
+                   (h[i].z - mean) * rstd * gg.z + bb.z, (h[i].w - mean) * rstd * gg.w + bb.w);
+        }
+    }
+}
+
+static void check_ln_shape(int C) {
+    if (C % 4 || C > 4 * 64 * LN_NI) { fprintf(stderr, "stn: LayerNorm width %d unsupported (C %% 4 == 0, C <= 1024)\n", C); abort(); }
+}
+
+void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L, int C, const float* w_t,
+                      const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y) {
+    check_ln_shape(C);
+    const int64_t M = (int64_t)B * L;
+    if (M == 0) return;
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (out_dtype == BF16)
+        hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
+                           ln_b, eps, static_cast<uint16_t*>(y));
+    else
+        hipLaunchKernelGGL((dwconv_ln_kernel<float, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b,
+                           eps, static_cast<float*>(y));
+}
+
+void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
+                      float eps, void* y) {
+    check_ln_shape(C);
+    if (M == 0) return;
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (out_dtype == BF16)
+        hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g,
+                           b, eps, static_cast<uint16_t*>(y));
+    else
+        hipLaunchKernelGGL((dwconv_ln_kernel<float, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g, b,
+                           eps, static_cast<float*>(y));
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb, int vocab, int L, int C,
+                             const int* __restrict__ len, float* __restrict__ x) {
+    const int row = blockIdx.x, b = row / L, t = row - b * L;
+    const int64_t id = ids[row];
+    const bool ok = t < len[b] && id >= 0 && id < vocab;
+    const int C4 = C >> 2;
+    float4* o = reinterpret_cast<float4*>(x) + (int64_t)row * C4;
+    const float4* e = reinterpret_cast<const float4*>(emb) + (ok ? id : 0) * C4;
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = e[c];
+        o[c] = v;
+    }
+}
+void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab, int B, int L, int C, const int* len,
+                  float* x) {
+    if (B * L == 0) return;
+    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(64), 0, s, ids, emb, vocab, L, C, len, x);
+}
+
+__global__ void mask_to_len_kernel(const float* __restrict__ mask, int L, int* __restrict__ len) {
+    const int b = blockIdx.x;
+    float c = 0.f;
+    for (int t = threadIdx.x; t < L; t += 64) c += mask[(int64_t)b * L + t] > 0.5f ? 1.f : 0.f;
+    c = wave_sum(c);
+    if (threadIdx.x == 0) len[b] = (int)(c + 0.5f);
+}
+void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(mask_to_len_kernel, dim3(B), dim3(64), 0, s, mask, L, len);
+}
+
+template <typename OutT>
+__global__ void ncl_to_rows_kernel(const float* __restrict__ in, int C, int L, int64_t n, OutT* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][L][C]
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int t = (int)(r % L);
+    const int64_t b = r / L;
+    store1(out + i, in[(b * C + c) * L + t]);
+}
+void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out) {
+    const int64_t n = (int64_t)B * C * L;
+    if (n == 0) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (out_dtype == BF16) hipLaunchKernelGGL(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, n, static_cast<uint16_t*>(out));
+    else hipLaunchKernelGGL(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, n, static_cast<float*>(out));
+}
+
+template <typename OutT>
+__global__ void cast_kernel(const float* __restrict__ in, int64_t n, OutT* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store1(out + i, in[i]);
+}
+void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out) {
+    if (n == 0) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (out_dtype == BF16) hipLaunchKernelGGL(cast_kernel<uint16_t>, grid, dim3(256), 0, s, in, n, static_cast<uint16_t*>(out));
+    else hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, s, in, n, static_cast<float*>(out));
+}
+
+__global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, int ldv, int L, int C, int64_t n,
+                                  const int* __restrict__ len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int t = (int)(r % L);
+    const int b = (int)(r / L);
+    if (!len || t < len[b]) x[i] += v[(int64_t)b * ldv + c];
+}
+void launch_add_rowvec(hipStream_t s, float* x, const float* v, int ldv, int B, int L, int C, const int* len) {
+    const int64_t n = (int64_t)B * L * C;
+    if (n == 0) return;
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v, ldv, L, C, n, len);
+}
+
+__global__ void time_embed_kernel(const float* __restrict__ cur, const float* __restrict__ tot, int dim, float scale,
+                                  float* __restrict__ te) {
+    const int b = blockIdx.x, hd = dim >> 1;
+    const float t = cur[b] / tot[b] * scale;
+    for (int i = threadIdx.x; i < hd; i += blockDim.x) {
+        const float f = expf(-logf(10000.0f) * (float)i / (float)hd);
+        te[(int64_t)b * dim + i] = sinf(t * f);
+        te[(int64_t)b * dim + hd + i] = cosf(t * f);
+    }
+}
+void launch_time_embed(hipStream_t s, const float* cur, const float* tot, int B, int dim, float scale, float* te) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(64), 0, s, cur, tot, dim, scale, te);
+}
+
+// ---------------------------------------------------------------------------------------------
+// vocoder front: frame (b, t = l*ccf + j) channel c  <-  latent[b][j*ld + c][l];   conv ld -> C, kernel k
+// 8 frames per workgroup; the (8 + k - 1) x ld input window sits in LDS; weights [ld*k][C] (co contiguous).
+// ---------------------------------------------------------------------------------------------
+static constexpr int VI_FR = 8;
+__global__ __launch_bounds__(256) void vocoder_in_kernel(const float* __restrict__ latent, int L, int ld, int ccf,
+                                                         const float* __restrict__ w_t, const float* __restrict__ bias,
+                                                         int C, int k, float* __restrict__ x) {
+    extern __shared__ __attribute__((aligned(16))) float win[];  // [(VI_FR + k - 1)][ld]
+    const int T = L * ccf, D = ld * ccf;
+    const int tiles = (T + VI_FR - 1) / VI_FR;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * VI_FR;
+    const int half = (k - 1) >> 1, nwin = VI_FR + k - 1;
+    for (int i = threadIdx.x; i < nwin * ld; i += blockDim.x) {
+        const int f = i / ld, c = i - f * ld;
+        const int t = t0 - half + f;
+        float v = 0.f;
+        if (t >= 0 && t < T) {
+            const int l = t / ccf, j = t - l * ccf;
+            v = latent[((int64_t)b * D + j * ld + c) * L + l];
+        }
+        win[i] = v;
+    }
+    __syncthreads();
+    for (int co = threadIdx.x; co < C; co += blockDim.x) {
+        float acc[VI_FR];
+        const float bv = bias[co];
+#pragma unroll
+        for (int f = 0; f < VI_FR; ++f) acc[f] = bv;
+        for (int ci = 0; ci < ld; ++ci)
+            for (int j = 0; j < k; ++j) {
+                const float wv = w_t[(int64_t)(ci * k + j) * C + co];
+#pragma unroll
+                for (int f = 0; f < VI_FR; ++f) acc[f] = fmaf(wv, win[(f + j) * ld + ci], acc[f]);
+            }
+#pragma unroll
+        for (int f = 0; f < VI_FR; ++f)
+            if (t0 + f < T) x[((int64_t)b * T + t0 + f) * C + co] = acc[f];
+    }
+}
+void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld, int ccf, const float* w_t,
+                       const float* bias, int C, int k, float* x) {
+    const int T = L * ccf;
+    if (B * T == 0) return;
+    const int tiles = (T + VI_FR - 1) / VI_FR;
+    const size_t lds = sizeof(float) * (size_t)(VI_FR + k - 1) * ld;
+    hipLaunchKernelGGL(vocoder_in_kernel, dim3(B * tiles), dim3(256), lds, s, latent, L, ld, ccf, w_t, bias, C, k, x);
+}
+
+template <typename InT>
+__global__ void masked_mean_kernel(const InT* __restrict__ x, int L, int C, const int* __restrict__ len,
+                                   float* __restrict__ pooled) {
+    const int b = blockIdx.x, n = len[b];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < n; ++t) s += load1(x + ((int64_t)b * L + t) * C + c);
+        pooled[(int64_t)b * C + c] = s / (float)(n > 0 ? n : 1);
+    }
+}
+void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled) {
+    if (B == 0) return;
+    if (in_dtype == BF16) hipLaunchKernelGGL(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled);
+    else hipLaunchKernelGGL(masked_mean_kernel<float>, dim3(B), dim3(128), 0, s, static_cast<const float*>(x), L, C, len, pooled);
+}
+
+__global__ void softplus_kernel(float* x, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float y = x[i]; x[i] = y > 20.f ? y : log1pf(expf(y)); }
+}
+void launch_softplus(hipStream_t s, float* x, int n) {
+    if (n) hipLaunchKernelGGL(softplus_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
+}
+__global__ void scale_kernel(float* x, int n, float mul) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= mul;
+}
+void launch_scale(hipStream_t s, float* x, int n, float mul) {
+    if (n) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, mul);
+}
+__global__ void reciprocal_kernel(const float* in, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 1.0f / in[i];
+}
+void launch_reciprocal(hipStream_t s, const float* in, int n, float* out) {
+    if (n) hipLaunchKernelGGL(reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, out);
+}
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf2f_(in[i]);
+}
+void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out) {
+    if (n) hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+}
+__global__ void fill_kernel(float* x, int n, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+void launch_fill(hipStream_t s, float* x, int n, float v) {
+    if (n) hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller; element (utt, d, t) depends only on (seed, utt, d, t)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ void randn_masked_kernel(unsigned long long seed, const int64_t* __restrict__ utt_ids, int D, int L,
+                                    const int* __restrict__ len, int64_t n4, float* __restrict__ xt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][D][ceil(L/4)]
+    if (i >= n4) return;
+    const int L4 = (L + 3) >> 2;
+    const int t4 = (int)(i % L4);
+    const int64_t r = i / L4;
+    const int d = (int)(r % D);
+    const int b = (int)(r / D);
+    const unsigned long long u = utt_ids ? (unsigned long long)utt_ids[b] : (unsigned long long)b;
+    unsigned c[4] = {(unsigned)t4, (unsigned)d, (unsigned)u, (unsigned)(u >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    float nrm[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float rr = sqrtf(-2.0f * logf(u1)), th = 6.28318530717958647692f * u2;
+        nrm[2 * h] = rr * cosf(th);
+        nrm[2 * h + 1] = rr * sinf(th);
+    }
+    const int nb = len ? len[b] : L;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = t4 * 4 + q;
+        if (t < L) xt[((int64_t)b * D + d) * L + t] = t < nb ? nrm[q] : 0.f;
+    }
+}
+void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, int B, int D, int L, const int* len,
+                         float* xt) {
+    const int64_t n4 = (int64_t)B * D * ((L + 3) / 4);
+    if (n4 == 0) return;
+    hipLaunchKernelGGL(randn_masked_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (unsigned long long)seed,
+                       utt_ids, D, L, len, n4, xt);
+}
+
+__global__ void mask_ncl_kernel(float* __restrict__ x, int D, int L, int64_t n, const int* __restrict__ len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = (int)(i % L);
+    const int b = (int)(i / ((int64_t)D * L));
+    if (t >= len[b]) x[i] = 0.f;
+}
+void launch_mask_ncl(hipStream_t s, float* x, int B, int D, int L, const int* len) {
+    const int64_t n = (int64_t)B * D * L;
+    if (n == 0) return;
+    hipLaunchKernelGGL(mask_ncl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, D, L, n, len);
+}
+
+__global__ void pcm16_kernel(const float* __restrict__ w, int64_t n, int16_t* __restrict__ pcm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = fminf(1.0f, fmaxf(-1.0f, w[i]));
+    pcm[i] = (int16_t)(int)(c * 32767.0f);  // truncation toward zero, as static_cast<int16_t> in the reference
+}
+void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t n, int16_t* pcm) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, pcm);
+}
+
+}  // namespace stn

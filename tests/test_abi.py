@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/stn.h declares, and refuses to run without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from supertonic_amd import binding
+from supertonic_amd.arch import StnArch, default_arch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "stn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(stn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    lib = binding.load()
+    names = _declared()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert b"gfx950" in lib.stn_version()
+
+
+def test_arch_struct_layout_matches_header():
+    # sizeof(stn_arch) from the header: 36 ints + 16 ints + 5 floats
+    assert ctypes.sizeof(StnArch) == 4 * (36 + 16 + 5)
+    a = default_arch()
+    assert a.latent_channels == 144 and a.chunk_size == 3072
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(binding.StnError) as ei:
+        binding.Engine(0, "bf16")
+    assert "no HIP device" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through oracle/ (that would void every parity claim)."""
+    pkg = os.path.join(ROOT, "supertonic_amd")
+    banned = ("import oracle", "from oracle", "stn_ref", "libstnref", "neural_ref", "host_ref")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                hits = [b for b in banned if b in txt]
+                assert not hits, (f, hits)

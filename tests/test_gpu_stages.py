@@ -1,0 +1,165 @@
+"""Stage-level and end-to-end parity on a real MI355X, through the C ABI, against the CPU oracle
+(oracle/stn_ref.c) on identical synthetic weights, identical inputs and injected noise.
+
+Stated tolerances (max |diff| and rms diff, both relative to the rms of the oracle output):
+  fp32 engine : per stage max <= 2e-4 ; end-to-end waveform max <= 2e-3 (5 Euler steps + vocoder compound)
+  bf16 engine : per stage rms <= 2e-2, max <= 1e-1 ; end-to-end rms <= 5e-2
+(bf16 = bf16 GEMM operands and inter-kernel activations, fp32 accumulate, fp32 residual stream.)"""
+import numpy as np
+import pytest
+
+from oracle import host_ref
+from oracle.neural_ref import RefModel, randn
+from supertonic_amd import binding
+from supertonic_amd.arch import default_arch, tiny_arch
+from gpu_util import make_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": dict(stage_max=2e-4, stage_rms=5e-5, e2e_max=2e-3, e2e_rms=5e-4),
+       "bf16": dict(stage_max=1e-1, stage_rms=2e-2, e2e_max=3e-1, e2e_rms=5e-2)}
+
+
+@pytest.fixture(scope="module")
+def ref_tiny():
+    return RefModel(tiny_arch(), 7)
+
+
+@pytest.fixture(scope="module", params=["f32", "bf16"])
+def eng_tiny(request):
+    e = binding.Engine(0, request.param)
+    e.load_synthetic(tiny_arch(), 7)
+    e.mode = request.param
+    return e
+
+
+def check(got, ref, tol_max, tol_rms, what):
+    mx, rms = rel_err(got, ref)
+    assert np.all(np.isfinite(got)), what
+    assert mx <= tol_max and rms <= tol_rms, f"{what}: max {mx:.3e} (tol {tol_max}) rms {rms:.3e} (tol {tol_rms})"
+
+
+def test_param_count_matches_oracle(eng_tiny, ref_tiny):
+    assert eng_tiny.param_count == ref_tiny.param_count
+
+
+def test_duration(eng_tiny, ref_tiny):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5])
+    t = TOL[eng_tiny.mode]
+    check(eng_tiny.duration(ids, sdp, mask), ref_tiny.duration(ids, sdp, mask), t["stage_max"], t["stage_rms"], "duration")
+
+
+def test_text_enc(eng_tiny, ref_tiny):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5])
+    got, ref = eng_tiny.text_enc(ids, sttl, mask), ref_tiny.text_enc(ids, sttl, mask)
+    t = TOL[eng_tiny.mode]
+    check(got, ref, t["stage_max"], t["stage_rms"], "text_emb")
+    assert np.all(got[1, :, 9:] == 0) and np.all(got[2, :, 5:] == 0)  # padded tokens are exactly zero
+
+
+def test_vector_est(eng_tiny, ref_tiny):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5])
+    emb = ref_tiny.text_enc(ids, sttl, mask)
+    L = 9
+    lmask = host_ref.length_to_mask([9, 5, 2], L)
+    x = randn(5, 3, a.latent_channels, L) * lmask
+    ts, cs = np.full(3, 4, np.float32), np.array([0, 1, 3], np.float32)
+    got = eng_tiny.vector_est(x, emb, sttl, mask, lmask, ts, cs)
+    ref = ref_tiny.vector_est(x, emb, sttl, mask, lmask, ts, cs)
+    t = TOL[eng_tiny.mode]
+    check(got, ref, t["stage_max"], t["stage_rms"], "denoised_latent")
+    assert np.all(got[1, :, 5:] == 0) and np.all(got[2, :, 2:] == 0)
+
+
+def test_vocoder(eng_tiny, ref_tiny):
+    a = tiny_arch()
+    lat = randn(11, 2, a.latent_channels, 7)
+    t = TOL[eng_tiny.mode]
+    check(eng_tiny.vocoder(lat), ref_tiny.vocoder(lat), t["stage_max"], t["stage_rms"], "wav")
+
+
+def test_synthesize_end_to_end_injected_noise(eng_tiny, ref_tiny):
+    """Whole TextToSpeech::_infer path (cpp/helper.cpp:469-683): DP -> /speed -> TE -> noise -> 3x VE -> vocoder."""
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 16, [16, 11, 6], seed=3)
+    durs = np.array([0.35, 0.20, 0.08], np.float32)  # override keeps L identical on both sides
+    noise = {}
+
+    def nf(B, D, L):
+        noise["x"] = randn(77, B, D, L)
+        return noise["x"]
+
+    ref_wav, ref_dur = ref_tiny.synthesize(ids, mask, sttl, sdp, 3, 1.05, nf, duration_override=durs)
+    wav, dur = eng_tiny.synthesize(ids, mask, sttl, sdp, 3, 1.05, noise=noise["x"], duration_override=durs)
+    assert wav.shape == ref_wav.shape
+    np.testing.assert_allclose(dur, ref_dur, rtol=1e-6)
+    t = TOL[eng_tiny.mode]
+    check(wav, ref_wav, t["e2e_max"], t["e2e_rms"], "e2e wav")
+
+
+def test_synthesize_predicted_durations_and_device_noise(eng_tiny, ref_tiny):
+    """No override, no injected noise: durations come from the DP stage, noise from the on-device Philox."""
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 2, 12, [12, 8], seed=9)
+    wav, dur = eng_tiny.synthesize(ids, mask, sttl, sdp, 2, 1.0, noise_seed=42)
+    ref_wav, ref_dur = ref_tiny.synthesize(ids, mask, sttl, sdp, 2, 1.0, lambda B, D, L: randn(42, B, D, L))
+    t = TOL[eng_tiny.mode]
+    np.testing.assert_allclose(dur, ref_dur, rtol=max(t["stage_max"], 1e-5))
+    if wav.shape == ref_wav.shape:  # bf16 durations may land on the other side of a frame boundary
+        check(wav, ref_wav, t["e2e_max"], t["e2e_rms"], "e2e wav (device noise)")
+    else:
+        assert eng_tiny.mode == "bf16"
+
+
+def test_sharding_invariance(eng_tiny):
+    """An utterance synthesized alone (as on another GPU rank) equals the same utterance inside a batch:
+    noise is keyed by utterance id, masked stages ignore batch mates.  The vocoder is unmasked in the
+    reference contract, so only the common valid prefix is compared, away from the padded tail."""
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 12, [12, 12, 12], seed=4)
+    durs = np.array([0.21, 0.21, 0.21], np.float32)
+    wav, _ = eng_tiny.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=durs, noise_seed=5, utt_ids=[10, 11, 12])
+    w1, _ = eng_tiny.synthesize(ids[1:2], mask[1:2], sttl[1:2], sdp[1:2], 2, 1.0, duration_override=durs[1:2],
+                                noise_seed=5, utt_ids=[11])
+    mx, _ = rel_err(w1[0], wav[1])
+    assert mx < (1e-5 if eng_tiny.mode == "f32" else 1e-5), mx  # same kernels, same data -> same bits up to tile order
+
+
+def test_error_paths(eng_tiny):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 2, 8, [8, 8])
+    with pytest.raises(binding.StnError):
+        eng_tiny.synthesize(ids, mask, sttl, sdp, 0, 1.05)  # total_step < 1
+    with pytest.raises(binding.StnError):
+        eng_tiny.synthesize(ids, mask, sttl, sdp, 2, 0.0)  # speed <= 0
+    with pytest.raises(binding.StnError):
+        eng_tiny.load_dir("/nonexistent/onnx")  # missing assets -> "Failed to open ..." like cpp/helper.cpp:805
+    e2 = binding.Engine(0, "f32")
+    with pytest.raises(binding.StnError):
+        e2.vocoder(np.zeros((1, 144, 2), np.float32))  # no model loaded
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_model_single_utterance(mode):
+    """BASELINE.json configs[0]/[1] shape: one 10-word sentence (62 tokens, 3.37 s -> L=49), the 66 M stack."""
+    a = default_arch()
+    ref = RefModel(a, 7)
+    eng = binding.Engine(0, mode)
+    eng.load_synthetic(a, 7)
+    assert eng.param_count == ref.param_count and abs(eng.param_count - 66e6) / 66e6 < 0.10
+    ids, mask, sttl, sdp = make_inputs(a, 1, 62, [62], seed=1)
+    durs = np.array([53 / 15.0], np.float32)
+    nz = {}
+
+    def nf(B, D, L):
+        nz["x"] = randn(1234, B, D, L)
+        return nz["x"]
+
+    ref_wav, ref_dur = ref.synthesize(ids, mask, sttl, sdp, 5, 1.05, nf, duration_override=durs)
+    wav, dur = eng.synthesize(ids, mask, sttl, sdp, 5, 1.05, noise=nz["x"], duration_override=durs)
+    assert wav.shape == (1, 49 * 3072)
+    t = TOL[mode]
+    check(wav, ref_wav, t["e2e_max"], t["e2e_rms"], "C1 wav")
