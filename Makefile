@@ -8,10 +8,13 @@ HOSTSRC := $(CSRC)/engine.cpp $(CSRC)/api.cpp $(wildcard $(CSRC)/host/*.cpp)
 OBJS    := $(patsubst %.hip,build/%.o,$(KERNELS)) $(patsubst %.cpp,build/%.o,$(HOSTSRC))
 HDRS    := $(wildcard $(CSRC)/*.hpp $(CSRC)/host/*.hpp include/*.h)
 
-all: supertonic_amd/libstn.so oracle
+all: supertonic_amd/libstn.so supertonic_amd/example_native oracle
 
 supertonic_amd/libstn.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+supertonic_amd/example_native: $(CSRC)/cli/example_native.cpp supertonic_amd/libstn.so $(HDRS)
+	$(HIPCC) -O2 -std=c++17 -Iinclude -o $@ $< -Lsupertonic_amd -lstn -Wl,-rpath,'$$ORIGIN'
 
 build/%.o: %.hip $(HDRS)
 	@mkdir -p $(dir $@)
@@ -25,7 +28,7 @@ oracle:
 	$(MAKE) -C oracle -s
 
 clean:
-	rm -rf build supertonic_amd/libstn.so
+	rm -rf build supertonic_amd/libstn.so supertonic_amd/example_native
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

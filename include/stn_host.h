@@ -1,0 +1,47 @@
+/* stn_host.h — C ABI of the host-side text path (same library, libstn.so; no GPU needed by these).
+ *
+ * Each function replaces a piece of the reference's C++ host (paths relative to /root/reference):
+ *   stn_text_preprocess    UnicodeProcessor::preprocessText           cpp/helper.cpp:52-200
+ *   stn_text_to_ids        UnicodeProcessor::call                     cpp/helper.cpp:355-390
+ *   stn_latent_geometry    TextToSpeech::sampleNoisyLatent (shapes)   cpp/helper.cpp:424-440,457 + getLatentMask :759-770
+ *   stn_chunk_text         chunkText                                  cpp/helper.cpp:1117-1186
+ *   stn_sanitize_filename  sanitizeFilename                           cpp/helper.cpp:1070-1111
+ *   stn_wav_encode / stn_write_wav   writeWavFile                     cpp/helper.cpp:943-990
+ * Strings are UTF-8, NUL-terminated.  Functions that produce text return the number of bytes needed
+ * (excluding the NUL) and write at most `cap` bytes; a negative return is an STN_ERR_* code and
+ * stn_host_last_error() holds the message (thread-local).
+ */
+#ifndef STN_HOST_H
+#define STN_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* stn_host_last_error(void);
+
+int64_t stn_text_preprocess(const char* text, const char* lang, char* out, size_t cap);
+
+/* ids_out [B][Lt_cap] (row stride Lt_cap), lengths_out [B]; *Lt_out = max length.  If Lt_cap is too small
+ * nothing is written to ids_out and *Lt_out tells the size to allocate (call twice). */
+int stn_text_to_ids(const int64_t* indexer, size_t indexer_len, const char* const* texts, const char* const* langs,
+                    int B, int64_t* ids_out, int Lt_cap, int32_t* lengths_out, int* Lt_out);
+
+int stn_latent_geometry(const float* duration, int B, int sample_rate, int base_chunk_size, int chunk_compress_factor,
+                        int latent_dim, int* D_out, int* L_out, int32_t* latent_lengths_out);
+
+/* chunks are written back to back, each NUL-terminated; returns bytes needed, *n_chunks = count */
+int64_t stn_chunk_text(const char* text, int max_len, char* out, size_t cap, int* n_chunks);
+
+int64_t stn_sanitize_filename(const char* text, int max_len, char* out, size_t cap);
+
+/* 44-byte RIFF header + int16 PCM; returns bytes needed (44 + 2n) */
+int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap);
+int stn_write_wav(const char* path, const float* audio, size_t n, int sample_rate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STN_HOST_H */

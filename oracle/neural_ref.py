@@ -20,13 +20,26 @@ def build():
     subprocess.run(["make", "-C", _HERE, "-s"], check=True)
 
 
+def default_threads():
+    """Threads the oracle may use: the CPU affinity of this process, capped at 16 (a GPU box's CPU share);
+    the host may have hundreds of cores the container is not allowed to use."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("STN_ORACLE_THREADS", "16"))))
+
+
 def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libstnref.so")
         if not os.path.exists(path):
             build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = ctypes.CDLL(path)
+        L.stnref_set_threads.argtypes = [ctypes.c_int]
+        L.stnref_set_threads(default_threads())
         vp, ci = ctypes.c_void_p, ctypes.c_int
         L.stnref_create.restype = vp
         L.stnref_create.argtypes = [ctypes.POINTER(StnArch), ctypes.c_uint64]
@@ -133,6 +146,10 @@ class RefModel:
         for s in range(total_step):
             xt = self.vector_est(xt, emb, style_ttl, text_mask, lmask, ts, np.full(B, s, np.float32))
         return self.vocoder(xt), dur
+
+
+def threads():
+    return lib().stnref_get_threads()
 
 
 def randn(seed, B, D, L, utt_ids=None):

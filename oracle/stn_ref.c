@@ -30,6 +30,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------------------ */
 /* deterministic synthetic weights                                                       */
@@ -171,6 +174,22 @@ static void declare_all(stnref_model* m) {
     for (int i = 0; i < a->vo_blocks; ++i) { snprintf(p, sizeof p, "vo.blk%d", i); declare_convnext(m, p, a->vo_dim, a->vo_hidden, a->vo_kernel); }
     declare_ln(m, "vo.out_ln", a->vo_dim);
     declare_linear(m, "vo.head", a->base_chunk_size, a->vo_dim, a->head_gain);
+}
+
+/* bound the OpenMP team: a container's CPU quota is usually far below the host's core count */
+void stnref_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int stnref_get_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 stnref_model* stnref_create(const stn_arch* a, uint64_t seed) {

@@ -10,6 +10,8 @@ extern "C" {
 
 typedef struct stnref_model stnref_model;
 
+void stnref_set_threads(int n);
+int stnref_get_threads(void);
 stnref_model* stnref_create(const stn_arch* a, uint64_t seed);
 void stnref_destroy(stnref_model* m);
 int64_t stnref_param_count(const stnref_model* m);

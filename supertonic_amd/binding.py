@@ -114,6 +114,10 @@ class Engine:
         except Exception:
             pass
 
+    def _need_model(self):
+        if self.arch is None:
+            raise StnError(-3, "no model loaded: call load_synthetic or load_dir first")
+
     def _ck(self, rc):
         if rc < 0:
             raise StnError(rc, self._lib.stn_last_error(self._h).decode())
@@ -133,6 +137,7 @@ class Engine:
 
     # ---- the four former Run sites ----------------------------------------------------------------
     def duration(self, text_ids, style_dp, text_mask):
+        self._need_model()
         B, Lt = text_ids.shape
         out = np.empty(B, np.float32)
         self._ck(self._lib.stn_duration(self._h, B, Lt, _c(text_ids, np.int64), _c(style_dp, np.float32),
@@ -140,6 +145,7 @@ class Engine:
         return out
 
     def text_enc(self, text_ids, style_ttl, text_mask):
+        self._need_model()
         B, Lt = text_ids.shape
         out = np.empty((B, self.arch.te_out_dim, Lt), np.float32)
         self._ck(self._lib.stn_text_enc(self._h, B, Lt, _c(text_ids, np.int64), _c(style_ttl, np.float32),
@@ -147,6 +153,7 @@ class Engine:
         return out
 
     def vector_est(self, noisy, text_emb, style_ttl, text_mask, latent_mask, total_step, current_step):
+        self._need_model()
         B, D, L = noisy.shape
         Lt = text_emb.shape[2]
         out = np.empty((B, D, L), np.float32)
@@ -157,6 +164,7 @@ class Engine:
         return out
 
     def vocoder(self, latent):
+        self._need_model()
         B, D, L = latent.shape
         out = np.empty((B, L * self.arch.chunk_size), np.float32)
         self._ck(self._lib.stn_vocoder(self._h, B, L, _c(latent, np.float32), out))

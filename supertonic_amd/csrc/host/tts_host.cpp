@@ -1,0 +1,169 @@
+#include "tts_host.hpp"
+
+#include <cmath>
+#include <fstream>
+#include <random>
+#include <stdexcept>
+
+#include "json_min.hpp"
+
+namespace stn {
+namespace host {
+
+namespace {
+std::string slurp(const std::string& path, const char* what) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error(std::string("Failed to open ") + what + ": " + path);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+void check(stn_handle* h, int rc) {
+    if (rc != STN_OK) throw std::runtime_error(std::string("engine: ") + stn_last_error(h));
+}
+}  // namespace
+
+Config loadCfgs(const std::string& onnx_dir) {
+    const json::Value j = json::parse(slurp(onnx_dir + "/tts.json", "config file"));
+    Config c;
+    c.ae.sample_rate = j.at("ae").at("sample_rate").as_int();
+    c.ae.base_chunk_size = j.at("ae").at("base_chunk_size").as_int();
+    c.ttl.chunk_compress_factor = j.at("ttl").at("chunk_compress_factor").as_int();
+    c.ttl.latent_dim = j.at("ttl").at("latent_dim").as_int();
+    return c;
+}
+
+Style loadVoiceStyle(const std::vector<std::string>& paths, bool verbose) {
+    if (paths.empty()) throw std::runtime_error("loadVoiceStyle: no voice style given");
+    std::vector<float> ttl, dp;
+    std::vector<int64_t> ttl_shape, dp_shape;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        const json::Value j = json::parse(slurp(paths[i], "voice style file"));
+        const json::Value& t = j.at("style_ttl");
+        const json::Value& d = j.at("style_dp");
+        if (i == 0) {  // dims of the first file define the batch layout (cpp/helper.cpp:840-846)
+            ttl_shape = {(int64_t)paths.size(), t.at("dims").at(1).as_int(), t.at("dims").at(2).as_int()};
+            dp_shape = {(int64_t)paths.size(), d.at("dims").at(1).as_int(), d.at("dims").at(2).as_int()};
+        }
+        const size_t nt = (size_t)(ttl_shape[1] * ttl_shape[2]), nd = (size_t)(dp_shape[1] * dp_shape[2]);
+        std::vector<float> a, b;
+        t.at("data").flatten_numbers(a);
+        d.at("data").flatten_numbers(b);
+        if (a.size() != nt || b.size() != nd) throw std::runtime_error("voice style " + paths[i] + ": data does not match dims");
+        ttl.insert(ttl.end(), a.begin(), a.end());
+        dp.insert(dp.end(), b.begin(), b.end());
+    }
+    if (verbose) std::cout << "Loaded " << paths.size() << " voice styles" << std::endl;
+    return Style(std::move(ttl), std::move(ttl_shape), std::move(dp), std::move(dp_shape));
+}
+
+Style syntheticVoiceStyle(const std::vector<std::string>& names, const stn_arch& a) {
+    std::vector<float> ttl, dp;
+    for (const std::string& nm : names) {
+        uint64_t seed = 1469598103934665603ULL;
+        for (unsigned char c : nm) { seed ^= c; seed *= 1099511628211ULL; }
+        std::mt19937_64 gen(seed);
+        std::normal_distribution<float> nd(0.f, 0.1f);
+        for (int i = 0; i < a.n_style_ttl * a.d_style_ttl; ++i) ttl.push_back(nd(gen));
+        for (int i = 0; i < a.n_style_dp * a.d_style_dp; ++i) dp.push_back(nd(gen));
+    }
+    const int64_t B = (int64_t)names.size();
+    return Style(std::move(ttl), {B, a.n_style_ttl, a.d_style_ttl}, std::move(dp), {B, a.n_style_dp, a.d_style_dp});
+}
+
+TextToSpeech::TextToSpeech(stn_handle* engine, UnicodeProcessor tp, const Config& cfgs, uint64_t noise_seed)
+    : h_(engine), text_processor_(std::move(tp)), cfgs_(cfgs), noise_seed_(noise_seed) {}
+TextToSpeech::~TextToSpeech() { stn_destroy(h_); }
+
+TextToSpeech::SynthesisResult TextToSpeech::infer(const std::vector<std::string>& text_list,
+                                                  const std::vector<std::string>& lang_list, const Style& style,
+                                                  int total_step, float speed) {
+    const int bsz = (int)text_list.size();
+    if (bsz != style.getTtlShape()[0]) throw std::runtime_error("Number of texts must match number of style vectors");
+    const TokenBatch tb = text_processor_(text_list, lang_list);
+    const std::vector<float> mask = tb.mask();
+    check(h_, stn_batch_upload(h_, bsz, tb.Lt, tb.ids.data(), mask.data(), style.getTtlData().data(),
+                               style.getDpData().data(), nullptr, nullptr));
+    uint64_t seed = noise_seed_;
+    if (seed == 0) { std::random_device rd; seed = ((uint64_t)rd() << 32) | rd(); }  // unseeded, like cpp/helper.cpp:442-444
+    else seed += calls_;
+    ++calls_;
+    check(h_, stn_batch_run(h_, total_step, speed, seed));
+    int B = 0, L = 0;
+    int64_t W = 0;
+    check(h_, stn_batch_dims(h_, &B, &L, &W));
+    SynthesisResult r;
+    r.wav.resize((size_t)B * W);
+    r.duration.resize(B);
+    check(h_, stn_batch_fetch(h_, r.wav.data(), r.wav.size(), r.duration.data()));
+    return r;
+}
+
+TextToSpeech::SynthesisResult TextToSpeech::call(const std::string& text, const std::string& lang, const Style& style,
+                                                 int total_step, float speed, float silence_duration) {
+    if (style.getTtlShape()[0] != 1) throw std::runtime_error("Single speaker text to speech only supports single style");
+    const std::vector<std::string> chunks = chunk_text(text, lang == "ko" ? 120 : 300);
+    SynthesisResult out;
+    float dur_cat = 0.f;
+    bool first = true;
+    for (const std::string& chunk : chunks) {
+        SynthesisResult r = infer({chunk}, {lang}, style, total_step, speed);
+        if (first) {
+            out.wav = std::move(r.wav);
+            dur_cat = r.duration[0];
+            first = false;
+        } else {  // untrimmed chunk waves joined by zeros (cpp/helper.cpp:706-715)
+            out.wav.insert(out.wav.end(), (size_t)(int)(silence_duration * (float)cfgs_.ae.sample_rate), 0.0f);
+            out.wav.insert(out.wav.end(), r.wav.begin(), r.wav.end());
+            dur_cat += r.duration[0] + silence_duration;
+        }
+    }
+    out.duration = {dur_cat};
+    return out;
+}
+
+TextToSpeech::SynthesisResult TextToSpeech::batch(const std::vector<std::string>& text_list,
+                                                  const std::vector<std::string>& lang_list, const Style& style,
+                                                  int total_step, float speed) {
+    return infer(text_list, lang_list, style, total_step, speed);
+}
+
+std::unique_ptr<TextToSpeech> loadTextToSpeech(const std::string& onnx_dir, bool use_gpu, const EngineOptions& opts) {
+    if (!use_gpu) throw std::runtime_error("CPU mode is not supported: this engine runs on MI355X only");
+    stn_config cfg{opts.device, opts.dtype};
+    stn_handle* h = nullptr;
+    if (stn_create(&cfg, &h) != STN_OK) throw std::runtime_error(std::string("engine: ") + stn_last_error(nullptr));
+    std::cout << "Using MI355X (HIP device " << opts.device << ", " << (opts.dtype == STN_DTYPE_BF16 ? "bf16" : "fp32")
+              << ") for inference" << std::endl;
+    try {
+        const int rc = stn_load_dir(h, onnx_dir.c_str());
+        bool synthetic = false;
+        Config cfgs;
+        UnicodeProcessor tp;
+        if (rc == STN_OK) {
+            cfgs = loadCfgs(onnx_dir);
+            tp = UnicodeProcessor::from_file(onnx_dir + "/unicode_indexer.json");
+        } else if (opts.allow_synthetic) {
+            std::cout << "  model assets unavailable (" << stn_last_error(h) << ")\n"
+                      << "  -> synthetic weights from the default architecture descriptor (seed " << opts.weight_seed << ")" << std::endl;
+            stn_arch a;
+            stn_arch_default(&a);
+            check(h, stn_load_synthetic(h, &a, opts.weight_seed));
+            cfgs.ae.sample_rate = a.sample_rate; cfgs.ae.base_chunk_size = a.base_chunk_size;
+            cfgs.ttl.chunk_compress_factor = a.chunk_compress_factor; cfgs.ttl.latent_dim = a.latent_dim;
+            std::vector<int64_t> idx(65536);  // synthetic indexer of the same shape as unicode_indexer.json
+            for (int cp = 0; cp < 65536; ++cp) idx[cp] = cp < 384 ? cp : 384 + (cp % 128);
+            tp = UnicodeProcessor(std::move(idx));
+            synthetic = true;
+        } else {
+            throw std::runtime_error(stn_last_error(h));
+        }
+        auto tts = std::make_unique<TextToSpeech>(h, std::move(tp), cfgs, opts.noise_seed);
+        if (synthetic) tts->markSynthetic();
+        return tts;
+    } catch (...) {
+        stn_destroy(h);
+        throw;
+    }
+}
+
+}  // namespace host
+}  // namespace stn
