@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: audio-seconds per second (RTF^-1) + p50 utterance latency,
+66 M-parameter model, batch = 128 utterances per GPU, bf16, 5 Euler steps (config C3).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one full synthesis of this rank's resident batch (DP -> text encoder -> noise -> 5x vector estimator ->
+vocoder) with every input already in HBM; for N > 1 the step also gathers the finished waveforms to rank 0 over
+RCCL.  Weak scaling: 128 utterances per GPU.  Synthetic text / styles / weights (no assets offline).
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="utterances per GPU")
+    ap.add_argument("--words", type=int, default=10)
+    ap.add_argument("--total-step", type=int, default=5)
+    ap.add_argument("--speed", type=float, default=1.05)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from supertonic_amd import binding, host, workload
+    from supertonic_amd.arch import default_arch
+    from supertonic_amd.dist import gather_waveforms, shard_by_length
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- workload: 128*N utterances, sorted by length and dealt round-robin ---------------------
+    arch = default_arch()
+    texts_all = workload.utterances(args.batch * world, args.words, seed=1234)
+    shards = shard_by_length([len(t) for t in texts_all], world)
+    mine = shards[rank]
+    texts = [texts_all[i] for i in mine]
+    up = host.UnicodeProcessor(host.synthetic_indexer())
+    ids, mask = up(texts, ["en"] * len(texts))
+    sttl, sdp = workload.synthetic_styles(arch, mine)
+    durs = workload.forced_durations(texts)
+
+    eng = binding.Engine(local, args.dtype)
+    eng.load_synthetic(arch, 7)
+    if world > 1:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)  # RCCL gather orders after the engine's kernels
+    eng.batch_upload(ids, mask, sttl, sdp, duration_override=durs, utt_ids=mine)
+
+    gather_buf = {}
+
+    def step():
+        eng.batch_run(args.total_step, args.speed, 1234)
+        if world > 1:
+            B, L, W = eng.batch_dims()
+            if gather_buf.get("shape") != (B, W):
+                gather_buf["wav"] = torch.empty((B, W), dtype=torch.float32, device=dev)
+                gather_buf["dur"] = torch.tensor(durs / args.speed, dtype=torch.float32, device=dev)
+                gather_buf["shape"] = (B, W)
+            eng.batch_copy_wav_device(gather_buf["wav"].data_ptr(), W)
+            gather_waveforms(gather_buf["wav"], gather_buf["dur"], dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (also sizes the workspace) + one fully profiled step to find the dominant kernel family ------
+    for _ in range(max(1, args.warmup)):
+        step()
+    fence()
+    dominant, fam_stats = None, {}
+    if not args.no_profile:
+        eng.profile_filter(None)
+        eng.profile_enable(True)
+        eng.profile_reset()
+        step()
+        fence()
+        fam_stats = eng.profile()
+        eng.profile_enable(False)
+        dominant = max(fam_stats, key=lambda k: fam_stats[k]["ms"])
+        eng.profile_filter(dominant)  # the timed region carries events around this family only
+        eng.profile_reset()
+        eng.profile_enable(True)
+
+    # ---- timed region: exactly K steps between barrier + synchronize ------------------------------------------
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    roof = None
+    if dominant:
+        st = eng.profile()[dominant]
+        eng.profile_enable(False)
+        avg_ms = st["ms"] / max(st["launches"], 1)
+        flops_per_launch = st["flops"] / max(st["launches"], 1)
+        bytes_per_launch = st["bytes"] / max(st["launches"], 1)
+        is_gemm = "gemm" in dominant or "attention" in dominant
+        if is_gemm:
+            peak = 2500.0 if args.dtype == "bf16" else 157.3
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4))
+        else:
+            ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4))
+        roof.update(kernel=dominant, avg_launch_us=round(avg_ms * 1e3, 2), launches_timed=st["launches"],
+                    algorithmic_flops_per_launch=flops_per_launch, algorithmic_bytes_per_launch=bytes_per_launch,
+                    traffic=_pmc_traffic(dominant))
+
+    # ---- p50 per-utterance latency: completion time of the batch that contains the utterance ---------------------
+    lat = []
+    for _ in range(min(5, max(2, args.steps))):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    p50 = float(np.median(lat))
+
+    audio_per_step_rank = float((durs / np.float32(args.speed)).sum())
+    if world > 1:
+        t = torch.tensor([audio_per_step_rank], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        audio_per_step = float(t.item())
+    else:
+        audio_per_step = audio_per_step_rank
+    value = audio_per_step * args.steps / elapsed
+
+    if rank == 0:
+        B, L, W = eng.batch_dims()
+        out = {
+            "metric": "audio-sec/sec (RTF^-1), 66M model, batch=128 per GPU",
+            "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"C3: batch={args.batch} {args.words}-word English utterances per GPU, "
+                                   f"{args.total_step} Euler steps, {args.dtype} (BASELINE.json configs[2])",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "total_step": args.total_step,
+                       "speed": args.speed, "params": eng.param_count, "text_tokens_max": int(ids.shape[1]),
+                       "latent_frames_max": L, "audio_sec_per_step": round(audio_per_step, 2),
+                       "weights": "synthetic (descriptor include/stn_arch.h, seed 7)",
+                       "parallelism": f"utterance-sharded x{world}, RCCL waveform gather" if world > 1 else "single GPU"},
+            "p50_latency_ms": round(p50, 3),
+            "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM)",
+            "roofline": roof,
+        }
+        if fam_stats:
+            tot = sum(v["ms"] for v in fam_stats.values())
+            out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in sorted(fam_stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from an offline `rocprofv3 --pmc` pass of this same command
+    (profiles/pmc_traffic.json, written by tools/pmc_summary.py); None until such a pass exists."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(kernel)
+        except Exception:
+            return None
+    return None
+
+
+def cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args):
+    """The CPU oracle (plain-C fp32 restatement, OpenMP) timed on a bounded sample of the SAME workload.
+    kind = "port": the reference's ORT-CPU path cannot run here (no ONNX Runtime, no ONNX graphs)."""
+    from oracle import neural_ref
+    n = min(args.cpu_sample, len(texts))
+    lens = mask[:n].sum(axis=(1, 2)).astype(int)
+    lt = int(lens.max())
+    ref = neural_ref.RefModel(arch, 7)
+    t0 = time.perf_counter()
+    _, d = ref.synthesize(ids[:n, :lt], mask[:n, :, :lt], sttl[:n], sdp[:n], args.total_step, args.speed,
+                          lambda B, D, L: neural_ref.randn(1234, B, D, L), duration_override=durs[:n])
+    dt = time.perf_counter() - t0
+    return {"value": round(float(d.sum()) / dt, 2), "unit": "audio-sec/sec", "cores": neural_ref.threads(), "kind": "port",
+            "sample": f"first {n} utterances of the same batch as one padded batch, fp32, {args.total_step} Euler steps, "
+                      f"{dt:.1f} s wall on {neural_ref.threads()} OpenMP threads (oracle/stn_ref.c)"}
+
+
+if __name__ == "__main__":
+    main()

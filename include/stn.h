@@ -93,10 +93,18 @@ int stn_batch_fetch_latent(stn_handle* h, float* latent /*[B,D,L]*/);
 /* device pointer of the finished waveform [B, L*cs] float32 (valid until the next upload/run) */
 int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr);
 int stn_sync(stn_handle* h);
+/* enqueue on a caller-owned HIP stream (hipStream_t passed as void*; NULL = the handle's own stream), e.g. the
+ * framework stream that also carries the RCCL gather of the finished waveforms */
+int stn_set_stream(stn_handle* h, void* hip_stream);
+/* device->device copy of the finished waveform rows [B][W] into dst (row stride dst_stride floats >= W), enqueued
+ * on the handle's stream */
+int stn_batch_copy_wav_device(stn_handle* h, void* dst_device, int64_t dst_stride);
 
 /* ---- measurement: HIP-event timing of kernel families on the engine's own stream ------------------- */
 int stn_profile_enable(stn_handle* h, int on);
 int stn_profile_reset(stn_handle* h);
+/* time only one kernel family ("stage.kernel", e.g. "vo.gemm_pw1_gelu"); NULL or "" = all families */
+int stn_profile_filter(stn_handle* h, const char* family_or_null);
 /* number of kernel families seen; then per index: name, total ms, launches, algorithmic flops and bytes */
 int stn_profile_count(stn_handle* h);
 int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,

@@ -62,6 +62,9 @@ def load():
     L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
     L.stn_batch_wav_device_ptr.argtypes = [vp, ctypes.POINTER(vp)]
     L.stn_sync.argtypes = [vp]
+    L.stn_set_stream.argtypes = [vp, vp]
+    L.stn_batch_copy_wav_device.argtypes = [vp, vp, ctypes.c_int64]
+    L.stn_profile_filter.argtypes = [vp, ctypes.c_char_p]
     L.stn_profile_enable.argtypes = [vp, ci]
     L.stn_profile_reset.argtypes = [vp]
     L.stn_profile_count.argtypes = [vp]
@@ -212,6 +215,13 @@ class Engine:
     def sync(self):
         self._ck(self._lib.stn_sync(self._h))
 
+    def set_stream(self, hip_stream_ptr):
+        """Enqueue on a caller-owned HIP stream (int pointer, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._ck(self._lib.stn_set_stream(self._h, hip_stream_ptr))
+
+    def batch_copy_wav_device(self, dst_ptr, dst_stride):
+        self._ck(self._lib.stn_batch_copy_wav_device(self._h, dst_ptr, dst_stride))
+
     def synthesize(self, text_ids, text_mask, style_ttl, style_dp, total_step=5, speed=1.05, noise=None,
                    duration_override=None, noise_seed=1234, utt_ids=None):
         """TextToSpeech::_infer (/root/reference/cpp/helper.cpp:469-683) -> (wav [B, L*cs], duration [B])."""
@@ -224,6 +234,9 @@ class Engine:
     # ---- measurement -----------------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._ck(self._lib.stn_profile_enable(self._h, int(on)))
+
+    def profile_filter(self, family=None):
+        self._ck(self._lib.stn_profile_filter(self._h, family.encode() if family else None))
 
     def profile_reset(self):
         self._ck(self._lib.stn_profile_reset(self._h))

@@ -141,8 +141,13 @@ int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr) {
     return *ptr ? STN_OK : STN_ERR_STATE;
 }
 int stn_sync(stn_handle* h) { STN_TRY(h, { h->eng->sync(); }) }
+int stn_set_stream(stn_handle* h, void* hip_stream) { STN_TRY(h, { h->eng->set_stream(static_cast<hipStream_t>(hip_stream)); }) }
+int stn_batch_copy_wav_device(stn_handle* h, void* dst, int64_t stride) {
+    STN_TRY(h, { need(dst != nullptr, "dst is null"); h->eng->batch_copy_wav_device(static_cast<float*>(dst), stride); })
+}
 
 int stn_profile_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->profile_enable(on != 0); }) }
+int stn_profile_filter(stn_handle* h, const char* fam) { STN_TRY(h, { h->eng->profile_filter(fam ? fam : ""); }) }
 int stn_profile_reset(stn_handle* h) { STN_TRY(h, { h->eng->profile_reset(); h->prof.clear(); }) }
 int stn_profile_count(stn_handle* h) {
     if (!h) return STN_ERR_INVALID;

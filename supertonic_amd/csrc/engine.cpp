@@ -96,7 +96,13 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the engine has no CPU fallback");
     if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
     STN_HIP(hipSetDevice(device));
-    STN_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+    STN_HIP(hipStreamCreateWithFlags(&own_s_, hipStreamNonBlocking));
+    s_ = own_s_;
+}
+
+void Engine::set_stream(hipStream_t s) {
+    sync();
+    s_ = s ? s : own_s_;
 }
 
 void Engine::free_weights() {
@@ -114,7 +120,7 @@ Engine::~Engine() {
     for (void* p : batch_owned_) (void)hipFree(p);
     for (auto& sp : spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
-    if (s_) (void)hipStreamDestroy(s_);
+    if (own_s_) (void)hipStreamDestroy(own_s_);
 }
 
 DevTensor& Engine::tensor(const std::string& name) {
@@ -288,9 +294,12 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
 // profiling
 // =================================================================================================
 void Engine::prof_begin(const char* tag, double flops, double bytes) {
+    prof_active_ = false;
     if (!prof_on_ || spans_.size() > 200000) return;
+    std::string full = std::string(stage_) + "." + tag;
+    if (!prof_filter_.empty() && full != prof_filter_) return;
     ProfSpan sp;
-    sp.tag = tag;
+    sp.tag = std::move(full);
     sp.flops = flops;
     sp.bytes = bytes;
     auto get = [&]() {
@@ -303,10 +312,12 @@ void Engine::prof_begin(const char* tag, double flops, double bytes) {
     sp.b = get();
     STN_HIP(hipEventRecord(sp.a, s_));
     spans_.push_back(sp);
+    prof_active_ = true;
 }
 void Engine::prof_end() {
-    if (!prof_on_ || spans_.empty()) return;
+    if (!prof_active_) return;
     STN_HIP(hipEventRecord(spans_.back().b, s_));
+    prof_active_ = false;
 }
 void Engine::profile_reset() {
     sync();
@@ -413,6 +424,7 @@ void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, co
 // stages (device level)
 // =================================================================================================
 void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur) {
+    stage_ = "dp";
     const stn_arch& a = a_;
     const int C = a.dp_dim;
     const int64_t M = (int64_t)B * Lt;
@@ -439,6 +451,7 @@ void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_
 
 void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl,
                           void* rows) {
+    stage_ = "te";
     const stn_arch& a = a_;
     const int C = a.te_dim, Ce = a.te_out_dim;
     const int64_t M = (int64_t)B * Lt;
@@ -483,6 +496,7 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
 // K/V of the text and style contexts for every main block: invariant across Euler steps.
 // The returned buffers live in the arena ABOVE the caller's mark: the caller releases them.
 Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl) {
+    stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, nb = a.ve_main_blocks;
     VeCtx c;
@@ -499,6 +513,7 @@ Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const
 
 void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                          const float* total_step, const float* current_step, float* denoised) {
+    stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, D = a.latent_dim * a.chunk_compress_factor, nb = a.ve_main_blocks, H = a.ve_heads;
     const int64_t M = (int64_t)B * L;
@@ -567,6 +582,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
 }
 
 void Engine::vocoder_dev(int B, int L, const float* latent, float* wav) {
+    stage_ = "vo";
     const stn_arch& a = a_;
     const int C = a.vo_dim, T = L * a.chunk_compress_factor;
     const int64_t M = (int64_t)B * T;
@@ -821,6 +837,13 @@ void Engine::batch_fetch(float* wav, size_t wav_capacity, float* duration) {
     }
     sync();
     if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
+}
+void Engine::batch_copy_wav_device(float* dst, int64_t dst_stride) {
+    Batch& b = bt_;
+    const size_t W = (size_t)b.L * a_.base_chunk_size * a_.chunk_compress_factor;
+    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
+    if ((size_t)dst_stride < W) throw std::invalid_argument("dst_stride smaller than the waveform length");
+    STN_HIP(hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, b.wav, W * 4, W * 4, (size_t)b.B, hipMemcpyDeviceToDevice, s_));
 }
 void Engine::batch_fetch_latent(float* latent) {
     Batch& b = bt_;

@@ -71,6 +71,9 @@ class Engine {
     int dtype() const { return dt_; }
     hipStream_t stream() const { return s_; }
     void sync() { STN_HIP(hipStreamSynchronize(s_)); }
+    // run on a caller-owned stream (e.g. torch's current stream, so RCCL ops order after the engine's kernels);
+    // nullptr returns to the engine's own stream
+    void set_stream(hipStream_t s);
 
     // ---- device-level stages (all pointers device, enqueued on stream()) -------------------------
     // lengths are int32 [B] on device.
@@ -112,9 +115,12 @@ class Engine {
     const Batch& batch() const { return bt_; }
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
     void batch_fetch_latent(float* latent);  // final denoised latent [B,D,L] (tests)
+    // device->device: wav rows [B][W] into dst rows of stride dst_stride floats (>= W), on the engine's stream
+    void batch_copy_wav_device(float* dst, int64_t dst_stride);
 
     // ---- profiling (hipEvent pairs around launches of one kernel family, on this stream) ----------------
     void profile_enable(bool on) { prof_on_ = on; }
+    void profile_filter(const std::string& family) { prof_filter_ = family; }  // "" = every family
     void profile_reset();
     std::vector<std::pair<std::string, KernelStat>> profile_collect();
 
@@ -153,7 +159,10 @@ class Engine {
     void prof_end();
 
     int device_, dt_;
-    hipStream_t s_ = nullptr;
+    hipStream_t s_ = nullptr, own_s_ = nullptr;
+    const char* stage_ = "";
+    std::string prof_filter_;
+    bool prof_active_ = false;
     stn_arch a_{};
     bool loaded_ = false;
     int64_t params_ = 0;

@@ -1,0 +1,73 @@
+"""The N > 1 path on CPU: world_size-2 gloo run of the sharding + waveform gather used by bench.py
+(on MI355X the same code runs over RCCL), plus the sharding invariants."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from supertonic_amd import workload
+from supertonic_amd.dist import gather_waveforms, shard_by_length
+
+
+def test_shard_by_length_balances_and_partitions():
+    texts = workload.utterances(1024, min_words=4, max_words=48, seed=1234)  # C4: mixed lengths
+    lens = np.array([len(t) for t in texts])
+    shards = shard_by_length(lens, 8)
+    allidx = np.sort(np.concatenate(shards))
+    assert np.array_equal(allidx, np.arange(1024))  # a partition: nothing lost, nothing duplicated
+    assert all(len(s) == 128 for s in shards)
+    tot = np.array([lens[s].sum() for s in shards])
+    assert tot.max() / tot.min() < 1.02  # balanced total work
+    # length-sorted dealing keeps per-rank padding close to the global sorted order
+    assert all(np.all(np.diff(lens[s]) <= 0) for s in shards)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, W = (3, 40) if rank == 0 else (2, 56)  # ragged: row counts and lengths differ per rank
+        wav = torch.arange(B * W, dtype=torch.float32).reshape(B, W) + 1000 * rank
+        dur = torch.arange(B, dtype=torch.float32) + 10 * rank
+        wavs, durs = gather_waveforms(wav, dur, dst=0)
+        if rank == 0:
+            ok = len(wavs) == world
+            for r in range(world):
+                b, w = (3, 40) if r == 0 else (2, 56)
+                exp = torch.arange(b * w, dtype=torch.float32).reshape(b, w) + 1000 * r
+                ok = ok and torch.equal(wavs[r], exp) and torch.equal(durs[r], torch.arange(b, dtype=torch.float32) + 10 * r)
+            q.put(bool(ok))
+        else:
+            q.put(wavs is None and durs is None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_waveforms_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(res) and all(p.exitcode == 0 for p in procs)
+
+
+def test_workload_is_deterministic():
+    a, b = workload.utterances(16, 10), workload.utterances(16, 10)
+    assert a == b and all(t[0].isupper() and t.endswith(".") and len(t.split()) == 10 for t in a)
+    d = workload.forced_durations([workload.C1_SENTENCE])
+    assert abs(float(d[0]) - 53 / 15.0) < 1e-6  # 53 chars -> 3.53 s before /speed
