@@ -113,6 +113,8 @@ int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double*
 /* ---- op-level entry points used by the kernel parity tests (host pointers) -------------------------- */
 int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A /*[M,K]*/, const float* W /*[N,K]*/,
                 const float* bias_or_null, int act /*0 none,1 gelu,2 silu*/, float* out /*[M,N]*/);
+/* device-resident timing of one GEMM shape on random operands; mode 0 = bias+GELU store, 1 = residual epilogue */
+int stn_op_gemm_bench(stn_handle* h, int dtype, int M, int N, int K, int mode, int iters, double* avg_ms);
 int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x,
                      const float* w /*[C,k]*/, const float* bias, const float* ln_g, const float* ln_b, float* y);
 int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,

@@ -72,6 +72,7 @@ def load():
                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
                                   ctypes.POINTER(ctypes.c_double)]
     L.stn_op_gemm.argtypes = [vp, ci, ci, ci, ci, _f32p, _f32p, vp, ci, _f32p]
+    L.stn_op_gemm_bench.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     L.stn_op_dwconv_ln.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     L.stn_op_attention.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, vp, vp, ci, _f32p]
     L.stn_op_randn.argtypes = [vp, cu64, ci, ci, ci, vp, vp, _f32p]
@@ -262,6 +263,12 @@ class Engine:
         self._ck(self._lib.stn_op_gemm(self._h, self.dtype if dtype is None else _DTYPES[dtype], M, N, K,
                                        _c(A, np.float32), _c(W, np.float32), bptr, act, out))
         return out
+
+    def op_gemm_bench(self, M, N, K, mode=0, iters=20, dtype=None):
+        ms = ctypes.c_double()
+        self._ck(self._lib.stn_op_gemm_bench(self._h, self.dtype if dtype is None else _DTYPES[dtype], M, N, K, mode,
+                                             iters, ctypes.byref(ms)))
+        return ms.value
 
     def op_dwconv_ln(self, x, w, bias, g, b, dil, dtype=None):
         B, L, C = x.shape

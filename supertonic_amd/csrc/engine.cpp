@@ -923,6 +923,44 @@ void Engine::op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const
     sync();
 }
 
+double Engine::op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    const size_t esz = dtype == BF16 ? 2 : 4;
+    float* tmp = f32_alloc((size_t)std::max((size_t)M * K, (size_t)N * K));
+    void* A = ar_.alloc((size_t)M * K * esz);
+    void* Wt = ar_.alloc((size_t)N * K * esz);
+    launch_randn_masked(s_, 11, nullptr, 1, 1, (int)std::min<size_t>((size_t)M * K, 1u << 30), nullptr, tmp);
+    launch_cast(s_, dtype, tmp, (int64_t)M * K, A);
+    launch_randn_masked(s_, 12, nullptr, 1, 1, (int)std::min<size_t>((size_t)N * K, 1u << 30), nullptr, tmp);
+    launch_scale(s_, tmp, (int)std::min<size_t>((size_t)N * K, 1u << 30), 1.0f / std::sqrt((float)K));
+    launch_cast(s_, dtype, tmp, (int64_t)N * K, Wt);
+    float* bias = f32_alloc(N);
+    float* gamma = f32_alloc(N);
+    launch_fill(s_, bias, N, 0.01f);
+    launch_fill(s_, gamma, N, 0.2f);
+    float* resid = f32_alloc((size_t)M * N);
+    void* out = ar_.alloc((size_t)M * N * 4);
+    STN_HIP(hipMemsetAsync(resid, 0, (size_t)M * N * 4, s_));
+    Epilogue e;
+    e.bias = bias;
+    if (mode == 1) { e.mode = EPI_RESID; e.resid = resid; e.ldo = N; e.gamma = gamma; }
+    else { e.mode = EPI_STORE; e.act = ACT_GELU; e.out_dtype = dtype; e.out = out; e.ldo = N; }
+    for (int i = 0; i < 3; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
+    hipEvent_t a, b;
+    STN_HIP(hipEventCreate(&a));
+    STN_HIP(hipEventCreate(&b));
+    STN_HIP(hipEventRecord(a, s_));
+    for (int i = 0; i < iters; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
+    STN_HIP(hipEventRecord(b, s_));
+    STN_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    STN_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return (double)ms / iters;
+}
+
 void Engine::op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out) {
     STN_HIP(hipSetDevice(device_));
     ar_.reset();

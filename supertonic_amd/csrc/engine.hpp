@@ -130,6 +130,8 @@ class Engine {
                       const int* qlen, const int* klen, int rope_mode, float* o);
     void op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w, const float* bias,
                       const float* g, const float* b, float* y);
+    // device-resident timing of one GEMM shape (random operands), HIP events around `iters` launches: avg ms
+    double op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters);
     void op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out);
 
     Arena& arena() { return ar_; }

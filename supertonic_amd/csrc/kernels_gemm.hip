@@ -305,6 +305,168 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const float* __restrict
     run_epilogue<MODE>(e, acc, m0 + wm * 64, n0 + wn * 64, M, N, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 v2: LDS-DMA ring.  K % 32 == 0.
+//   K-step = 32 bf16 (64-B rows): stage = A 8 KiB + W 8 KiB; 4 stages = 64 KiB -> 2 workgroups per CU.
+//   Operands go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, hardware
+//   range check zero-fills rows past M / N); three stages stay in flight across raw s_barriers behind a
+//   COUNTED s_waitcnt vmcnt, so the per-CU ingest pipe never drains while the MFMAs run.
+//   LDS image: 16-B slot = chunk ^ ((row >> 2) & 3), applied on the per-lane SOURCE address (the DMA writes
+//   lane-linear) and again on the ds_read_b128 fragment reads: conflict-free 16-lane groups.
+//   Epilogue (STORE / RESID): accumulators -> LDS as fp32 [128][128] (the ring is dead by then) -> each lane
+//   owns 8 consecutive columns of a row: bias/GELU/residual on 16-B vectors, 16-B coalesced global stores.
+// ---------------------------------------------------------------------------------------------
+static constexpr int RK = 32, RSTAGES = 4, RSTAGE_BYTES = (BM + BN) * RK * 2;  // 16 KiB
+
+#define STN_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* __restrict__ A, int lda,
+                                                               const uint16_t* __restrict__ W, int ldw, int M, int N,
+                                                               int K, int tiles_n, int ntiles, Epilogue e) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RSTAGES * RSTAGE_BYTES];  // 64 KiB, the only LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A + (size_t)m0 * lda, m0 < M ? (size_t)(M - m0) * lda * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W + (size_t)n0 * ldw, n0 < N ? (size_t)(N - n0) * ldw * 2 : 0);
+
+    // this wave's DMA pieces: A pieces 2w, 2w+1 and W pieces 2w, 2w+1 (a piece = 16 rows x 64 B = 1 KiB)
+    unsigned offA[2], offW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (2 * wave + j) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);  // source-side swizzle
+        offA[j] = (unsigned)(row * lda + chunk * 8) * 2u;
+        offW[j] = (unsigned)(row * ldw + chunk * 8) * 2u;
+    }
+    const int nk = K / RK;
+
+#define STN_ISSUE(kt)                                                                                              \
+    {                                                                                                              \
+        unsigned char* st_ = smem + ((kt) & (RSTAGES - 1)) * RSTAGE_BYTES;                                         \
+        const int ko_ = (kt) * (RK * 2);                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, STN_LDS_PTR(st_ + (2 * wave + j) * 1024), 16, offA[j], ko_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, STN_LDS_PTR(st_ + BM * RK * 2 + (2 * wave + j) * 1024), 16, offW[j], ko_, 0, 0); \
+        }                                                                                                          \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    // prologue: up to three stages in flight
+    if (0 < nk) STN_ISSUE(0);
+    if (1 < nk) STN_ISSUE(1);
+    if (2 < nk) STN_ISSUE(2);
+
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most (stages still ahead) x 4 of this wave's DMAs remain outstanding
+        const int ahead = nk - 1 - kt;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of stage kt are in LDS; stage kt-1 is fully consumed
+        if (kt + 3 < nk) STN_ISSUE(kt + 3);  // refill the buffer that stage kt-1 just vacated
+        const unsigned char* sa = smem + (kt & (RSTAGES - 1)) * RSTAGE_BYTES;
+        const unsigned char* sb = sa + BM * RK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 2 + lh;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = wm * 64 + mi * 32 + lr;
+                a[mi] = *reinterpret_cast<const bf16x8*>(sa + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int row = wn * 64 + ni * 32 + lr;
+                b[ni] = *reinterpret_cast<const bf16x8*>(sb + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+#undef STN_ISSUE
+
+    if (!VEC || MODE >= EPI_EULER_T) {
+        run_epilogue<MODE>(e, acc, m0 + wm * 64, n0 + wn * 64, M, N, lane);
+        return;
+    }
+    // ---- LDS-staged epilogue -------------------------------------------------------------------------
+    __builtin_amdgcn_s_barrier();  // all fragment reads of the ring are done
+    float* S = reinterpret_cast<float*>(smem);  // [128][128] fp32
+    {
+        const int half = lane >> 5, cl = lane & 31;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = wm * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    S[row * BN + wn * 64 + ni * 32 + cl] = acc[mi][ni][i];
+                }
+    }
+    __syncthreads();
+    const int c8 = tid & 15;            // 8-column group inside the tile
+    const int n = n0 + c8 * 8;
+    if (n >= N) return;                 // whole column group out of range (N % 8 == 0 is guaranteed for VEC)
+    float bias[8], gam[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bias[j] = e.bias ? e.bias[n + j] : 0.f; gam[j] = (MODE == EPI_RESID && e.gamma) ? e.gamma[n + j] : 1.f; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = (tid >> 4) + 16 * q;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        float keep = 1.f;
+        if (e.len) { const int b = m / e.L; if (m - b * e.L >= e.len[b]) keep = 0.f; }
+        const float4 v0 = *reinterpret_cast<const float4*>(S + row * BN + c8 * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(S + row * BN + c8 * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const size_t o = (size_t)m * e.ldo + n;
+        if (MODE == EPI_STORE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = act_f(v[j] + bias[j], e.act) * keep;
+            if (e.out_dtype == BF16) {
+                uint4 pk;
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                pk.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                pk.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + o) = pk;
+            } else {
+                float* op = reinterpret_cast<float*>(e.out) + o;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {  // EPI_RESID
+            float* rp = e.resid + o;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+            const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j])) * keep;
+            *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(rp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
 void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                  const Epilogue& e) {
     if (M <= 0 || N <= 0) return;
@@ -316,8 +478,19 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
         abort();
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    // v2 ring kernel: bf16, K % 32 == 0.  Vectorised epilogue needs 16-B aligned 8-column groups.
+    const bool ring = dtype == BF16 && K % RK == 0;
+    const void* optr = e.mode == EPI_RESID ? static_cast<const void*>(e.resid) : e.out;
+    const bool vec = ring && e.mode <= EPI_RESID && N % 8 == 0 && e.ldo % 8 == 0 && !(reinterpret_cast<uintptr_t>(optr) & 15) &&
+                     (!e.bias || !(reinterpret_cast<uintptr_t>(e.bias) & 3));
 #define STN_LAUNCH(MODE)                                                                                         \
-    if (dtype == BF16)                                                                                           \
+    if (ring && vec)                                                                                             \
+        hipLaunchKernelGGL((gemm_bf16_ring_kernel<MODE, true>), dim3(ntiles), dim3(NT), 0, s,                    \
+                           static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e); \
+    else if (ring)                                                                                               \
+        hipLaunchKernelGGL((gemm_bf16_ring_kernel<MODE, false>), dim3(ntiles), dim3(NT), 0, s,                   \
+                           static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e); \
+    else if (dtype == BF16)                                                                                      \
         hipLaunchKernelGGL(gemm_bf16_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const uint16_t*>(A), \
                            lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e);              \
     else                                                                                                         \
