@@ -139,11 +139,211 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA attention (v_mfma_f32_32x32x16_bf16), head dim DH in {32, 64, 96}.
+//   workgroup = 4 waves = 128 queries of one (b, h); each wave owns 32 queries.
+//   LDS: Q [128][DH] and K [lk_pad][DH] as bf16 rows of DH*2+16 bytes (the +16 makes every ds_read_b128
+//   16-lane group hit 16 distinct slots), V TRANSPOSED [DH][lk_pad] with rows of lk_pad*2+8 bytes
+//   (conflict-free ds_read_b64 per 32-lane half).  RoPE + 1/sqrt(dh)*log2(e) are applied while staging.
+//   S^T = K Q^T is computed with the KEY on the accumulator rows and the QUERY on the lane, so the row max and
+//   the row sum are 16 in-register ops + one cross-half shuffle.  The exponentiated tile is then the A operand
+//   of O += P V with no lane movement (registers 8s..8s+7 = k-step s; element j <-> key 16s+8(j>>2)+4h+(j&3),
+//   which is exactly the order the transposed V image is read in).
+//   Softmax is two-pass (max, then exp/sum/PV with QK^T recomputed): sequences are <= ~320 keys, recomputing
+//   the small QK^T is cheaper than rescaling O (whose rows live in registers, not on the lane).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const unsigned ra = (ua + 0x7FFFu + ((ua >> 16) & 1u)) >> 16, rb = (ub + 0x7FFFu + ((ub >> 16) & 1u)) >> 16;
+    return ra | (rb << 16);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ q, int ldq,
+                                                        const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                        int ldk, uint16_t* __restrict__ o, int ldo, int Lq, int Lk,
+                                                        int lk_pad, const int* __restrict__ qlen,
+                                                        const int* __restrict__ klen, int rope_mode, float log_base,
+                                                        float gamma) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int QS = DH * 2 + 16;  // bytes per Q / K row
+    const int VS = lk_pad * 2 + 8;   // bytes per V^T row
+    unsigned char* Qs = lds_raw;
+    unsigned char* Ks = Qs + 128 * QS;
+    unsigned char* Vt = Ks + lk_pad * QS;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = klen ? min(klen[b], Lk) : Lk;
+    const int nq = qlen ? qlen[b] : Lq;
+    constexpr int HD2 = DH / 2;
+    const float qmul = rsqrtf((float)DH) * 1.44269504088896340736f;
+
+    // ---- stage Q and K (RoPE in fp32, stored bf16) -----------------------------------------------------
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint16_t* src = pass == 0 ? q + h * DH : k + h * DH;
+        const int ld = pass == 0 ? ldq : ldk;
+        const int64_t seq_base = pass == 0 ? (int64_t)b * Lq : (int64_t)b * Lk;
+        const int pos0 = pass == 0 ? q0 : 0, rows = pass == 0 ? 128 : lk_pad, limit = pass == 0 ? Lq : nk;
+        const int seq_len = pass == 0 ? nq : nk;
+        const float mul = pass == 0 ? qmul : 1.f;
+        unsigned char* dst = pass == 0 ? Qs : Ks;
+        for (int idx = tid; idx < rows * HD2; idx += 256) {
+            const int r = idx / HD2, i = idx - r * HD2;
+            const int pos = pos0 + r;
+            float x0 = 0.f, x1 = 0.f;
+            if (pos < limit) {
+                const uint16_t* p = src + (seq_base + pos) * ld;
+                x0 = __uint_as_float(((unsigned)p[i]) << 16);
+                x1 = __uint_as_float(((unsigned)p[i + HD2]) << 16);
+                if (rope_mode >= 0) {
+                    const float pp = rope_mode == 1 ? gamma * (float)pos / (float)(seq_len > 0 ? seq_len : 1) : (float)pos;
+                    const float inv = expf(-log_base * (float)(2 * i) / (float)DH);
+                    float sn, cs;
+                    sincosf(pp * inv, &sn, &cs);
+                    const float a0 = x0, a1 = x1;
+                    x0 = a0 * cs - a1 * sn;
+                    x1 = a1 * cs + a0 * sn;
+                }
+            }
+            uint16_t* row = reinterpret_cast<uint16_t*>(dst + r * QS);
+            row[i] = (uint16_t)pack_bf16x2(x0 * mul, 0.f);
+            row[i + HD2] = (uint16_t)pack_bf16x2(x1 * mul, 0.f);
+        }
+    }
+    // ---- stage V transposed ------------------------------------------------------------------------------
+    for (int idx = tid; idx < lk_pad * (DH / 8); idx += 256) {
+        const int key = idx / (DH / 8), c = idx - key * (DH / 8);
+        u32x4_t w = {0u, 0u, 0u, 0u};
+        if (key < nk) w = *reinterpret_cast<const u32x4_t*>(v + ((int64_t)b * Lk + key) * ldk + h * DH + c * 8);
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const unsigned word = w[e2];
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2) * VS + key * 2) = (uint16_t)(word & 0xFFFFu);
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2 + 1) * VS + key * 2) = (uint16_t)(word >> 16);
+        }
+    }
+    __syncthreads();
+    const int qbase = wave * 32;
+    if (q0 + qbase >= Lq) return;  // this wave's 32 queries are all padding (no barrier follows)
+
+    const int lr = lane & 31, lh = lane >> 5;
+    bf16x8_t bq[DH / 16];
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks)
+        bq[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + (qbase + lr) * QS + (ks * 2 + lh) * 16);
+
+    const int nkt = lk_pad >> 5;
+    float m = -1e30f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DH / 16; ++ks) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            m = fmaxf(m, key < nk ? acc[i] : -1e30f);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+
+    float lsum = 0.f;
+    f32x16_t oacc[DH / 32];
+#pragma unroll
+    for (int nd = 0; nd < DH / 32; ++nd)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[nd][i] = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DH / 16; ++ks) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+        }
+        float p[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            p[i] = key < nk ? exp2f(acc[i] - m) : 0.f;
+            lsum += p[i];
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            u32x4_t pw;
+            pw[0] = pack_bf16x2(p[8 * sidx + 0], p[8 * sidx + 1]);
+            pw[1] = pack_bf16x2(p[8 * sidx + 2], p[8 * sidx + 3]);
+            pw[2] = pack_bf16x2(p[8 * sidx + 4], p[8 * sidx + 5]);
+            pw[3] = pack_bf16x2(p[8 * sidx + 6], p[8 * sidx + 7]);
+            const bf16x8_t ap = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+            for (int nd = 0; nd < DH / 32; ++nd) {
+                const unsigned char* base = Vt + (nd * 32 + lr) * VS + (kt * 32 + 16 * sidx + 4 * lh) * 2;
+                const uint2 lo = *reinterpret_cast<const uint2*>(base);
+                const uint2 hi = *reinterpret_cast<const uint2*>(base + 16);
+                u32x4_t vw;
+                vw[0] = lo.x; vw[1] = lo.y; vw[2] = hi.x; vw[3] = hi.y;
+                oacc[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = (nk > 0 && lsum > 0.f) ? 1.0f / lsum : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int qrow = (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const float invq = __shfl(inv, qrow, 64);  // lane qrow (< 32) holds the sum of query qrow
+        const int gq = q0 + qbase + qrow;
+        if (gq < Lq) {
+            uint16_t* orow = o + ((int64_t)b * Lq + gq) * ldo + h * DH + lr;
+#pragma unroll
+            for (int nd = 0; nd < DH / 32; ++nd) orow[nd * 32] = (uint16_t)pack_bf16x2(oacc[nd][i] * invq, 0.f);
+        }
+    }
+}
+
+template <int DH>
+static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
+                             uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int lk_pad, size_t lds, const int* qlen,
+                             const int* klen, int rope_mode, float log_base, float gamma) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid((Lq + 127) / 128, H, B);
+    hipLaunchKernelGGL(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
+                       rope_mode, log_base, gamma);
+}
+
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
                       float rope_base, float rope_gamma) {
     if (B == 0 || Lq == 0) return;
     if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
+    if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15)) {
+        const int lk_pad = (Lk + 31) & ~31;
+        const size_t need = (size_t)128 * (dh * 2 + 16) + (size_t)lk_pad * (dh * 2 + 16) + (size_t)dh * (lk_pad * 2 + 8);
+        if (need <= 150 * 1024) {
+            const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
+            uint16_t* o16 = static_cast<uint16_t*>(o);
+            const float lb = logf(rope_base);
+            if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma);
+            else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma);
+            else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma);
+            return;
+        }
+    }
     const int ds = dh + 1;
     const size_t lds = sizeof(float) * ((size_t)(AQ + 2 * AK) * ds + (size_t)AQ * (AK + 1));
     const dim3 grid((Lq + AQ - 1) / AQ, H, B);
