@@ -43,7 +43,7 @@ static constexpr int STAGE_BYTES = (BM + BN) * 128;  // 32 KiB
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): GELU(x) = 0.5 x (1 + erf(x / sqrt2))
 __device__ __forceinline__ float gelu_f(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // 1 ulp; the A&S fit itself is 1.5e-7
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     const float erf_v = x < 0.f ? -erf_abs : erf_abs;
@@ -53,6 +53,43 @@ __device__ __forceinline__ float act_f(float v, int act) {
     if (act == ACT_GELU) return gelu_f(v);
     if (act == ACT_SILU) return v / (1.0f + expf(-v));
     return v;
+}
+// GELU for results that are about to be rounded to bf16 (8 significant bits): x * sigmoid(1.59577 x (1 + 0.044715 x^2)),
+// the tanh form written as a sigmoid — 5 VALU + v_exp_f32 + v_rcp_f32 instead of ~20 + 2.  |error| <= 3e-4 absolute,
+// below a bf16 ulp wherever |gelu(x)| > 0.08 and relatively tiny near 0.  fp32 outputs keep the erf form above.
+__device__ __forceinline__ float gelu_bf16_f(float x) {
+    const float t = x * fmaf(x * x, -0.10294324f, -2.30220819f);  // -(1.5957691 + 0.0713548 x^2) x * log2(e)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+__device__ __forceinline__ float act_out_f(float v, int act, bool to_bf16) {
+    if (act == ACT_GELU && to_bf16) return gelu_bf16_f(v);
+    return act_f(v, act);
+}
+// bias + activation + row mask on an 8-column group; the activation kind is resolved ONCE per group (a per-element
+// switch compiles to scalar branches around every element and triples the epilogue's issue time)
+__device__ __forceinline__ void act8(float (&v)[8], const float (&bias)[8], int act, bool to_bf16, float keep) {
+    if (act == ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] + bias[j]) * keep;
+    } else if (act == ACT_GELU && to_bf16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_bf16_f(v[j] + bias[j]) * keep;
+    } else if (act == ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j] + bias[j]) * keep;
+    } else if (act == 100) {  // experiments: plain VALU only
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t * fmaf(t * t, -0.1f, 0.5f) * keep; }
+    } else if (act == 101) {  // experiments: one v_exp_f32
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t * __builtin_amdgcn_exp2f(-t * t) * keep; }
+    } else if (act == 102) {  // experiments: one v_rcp_f32
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t * __builtin_amdgcn_rcpf(1.0f + t * t) * keep; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t / (1.0f + expf(-t)) * keep; }
+    }
 }
 __device__ __forceinline__ uint16_t f2bf(float f) {
     __hip_bfloat16 h = __float2bfloat16(f);
@@ -101,7 +138,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2]
                 if (n >= N) continue;
                 const float v = acc[mi][ni][i] + bias[ni];
                 if (MODE == EPI_STORE) {
-                    const float r = act_f(v, e.act) * keep;
+                    const float r = act_out_f(v, e.act, e.out_dtype == BF16) * keep;
                     const size_t o = (size_t)m * e.ldo + n;
                     if (e.out_dtype == BF16) reinterpret_cast<uint16_t*>(e.out)[o] = f2bf(r);
                     else reinterpret_cast<float*>(e.out)[o] = r;
@@ -441,8 +478,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const size_t o = (size_t)m * e.ldo + n;
         if (MODE == EPI_STORE) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = act_f(v[j] + bias[j], e.act) * keep;
+            act8(v, bias, e.act, e.out_dtype == BF16, keep);
             if (e.out_dtype == BF16) {
                 uint4 pk;
                 pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
@@ -467,6 +503,259 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 v3: the ring kernel generalised over the tile shape.  Per-CU operand ingest (L2/HBM -> LDS), not MFMA
+// issue, bounds the 128x128 tile (64 FLOP per ingested byte): a BM x BN tile needs (BM+BN)*64 B per 32-deep
+// K-step for 2*BM*BN*32 FLOP, so 256x256 halves the bytes per FLOP and 256x128 cuts them by a quarter.
+//   WM x WN wavefronts, each owning (TM*32) x (TN*32) of the tile; NSTAGE-deep LDS ring, NSTAGE-1 stages in flight.
+//   Epilogue: TM passes; pass mi stages the mi-th 32-row slab of every wave row ([WM*32][BN] fp32) through LDS and
+//   writes it out with 16-B vectors (STORE / RESID only, N % 8 == 0).
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA of one 1-KiB piece (16 B per lane).  Kept in a non-template function: with value-dependent arguments
+// the amdgcn builtin is re-checked at template instantiation on the HOST pass, fails there, and the failure is
+// swallowed as a substitution failure (the kernel silently loses its host stub).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, STN_LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N_ >= 0 && N_ < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+template <int PER, int D>  // wait until at most min(ahead, D) * PER of this wave's DMAs are outstanding
+__device__ __forceinline__ void wait_stage(int ahead) {
+    if constexpr (D >= 7) { if (ahead >= 7) { wait_vm<7 * PER>(); return; } }
+    if constexpr (D >= 6) { if (ahead >= 6) { wait_vm<6 * PER>(); return; } }
+    if constexpr (D >= 5) { if (ahead >= 5) { wait_vm<5 * PER>(); return; } }
+    if constexpr (D >= 4) { if (ahead >= 4) { wait_vm<4 * PER>(); return; } }
+    if constexpr (D >= 3) { if (ahead >= 3) { wait_vm<3 * PER>(); return; } }
+    if constexpr (D >= 2) { if (ahead >= 2) { wait_vm<2 * PER>(); return; } }
+    if constexpr (D >= 1) { if (ahead >= 1) { wait_vm<1 * PER>(); return; } }
+    wait_vm<0>();
+}
+
+template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_tiled_kernel(const uint16_t* __restrict__ A, int lda,
+                                                                        const uint16_t* __restrict__ W, int ldw, int M,
+                                                                        int N, int K, int tiles_n, int ntiles, Epilogue e) {
+    // KS = K elements per stage: 32 (64-B rows: half a cache line per DMA row segment) or 64 (full 128-B lines)
+    constexpr int NW = WM * WN, NTHR = NW * 64;
+    constexpr int TM = BM_ / WM / 32, TN = BN_ / WN / 32;
+    constexpr int ROWB = KS * 2;                 // bytes per LDS row
+    constexpr int RPP = 1024 / ROWB;             // rows per 1-KiB DMA piece (16 or 8)
+    constexpr int CPR = KS / 8;                  // 16-B chunks per row (4 or 8)
+    constexpr int PA = BM_ / RPP / NW, PW = BN_ / RPP / NW, PER = PA + PW;  // DMA pieces per wave per stage
+    constexpr int STAGE = (BM_ + BN_) * ROWB;
+    static_assert(KS == 32 || KS == 64, "KS");
+    static_assert(BM_ % (WM * 32) == 0 && BN_ % (WN * 32) == 0 && (BM_ / RPP) % NW == 0 && (BN_ / RPP) % NW == 0, "tile/wave shape");
+    static_assert(NSTAGE * STAGE >= WM * 32 * BN_ * 4, "epilogue slab must fit in the ring");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NSTAGE * STAGE bytes, the only LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int m0 = (tile / tiles_n) * BM_, n0 = (tile % tiles_n) * BN_;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A + (size_t)m0 * lda, m0 < M ? (size_t)(M - m0) * lda * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W + (size_t)n0 * ldw, n0 < N ? (size_t)(N - n0) * ldw * 2 : 0);
+    // swizzle of the 16-B slot inside a row: 64-B rows use (row>>2)&3, 128-B rows (row>>1)&7 (see the bank analysis above)
+    auto swz = [](int row) { return KS == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+    unsigned offA[PA], offW[PW];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int row = (PA * wave + j) * RPP + lane / CPR;
+        offA[j] = (unsigned)(row * lda + (((lane % CPR) ^ swz(row)) * 8)) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int row = (PW * wave + j) * RPP + lane / CPR;
+        offW[j] = (unsigned)(row * ldw + (((lane % CPR) ^ swz(row)) * 8)) * 2u;
+    }
+    const int nk = K / KS;
+
+#define STN_ISSUE(kt)                                                                                               \
+    {                                                                                                               \
+        unsigned char* st_ = smem + ((kt) % NSTAGE) * STAGE;                                                        \
+        const int ko_ = (kt) * ROWB;                                                                                \
+        _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                              \
+            dma16(rsA, st_ + (PA * wave + j) * 1024, offA[j], ko_);                                                  \
+        _Pragma("unroll") for (int j = 0; j < PW; ++j)                                                              \
+            dma16(rsW, st_ + BM_ * ROWB + (PW * wave + j) * 1024, offW[j], ko_);                                     \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+        if (st < nk) STN_ISSUE(st);
+
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_stage<PER, NSTAGE - 2>(nk - 1 - kt);
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < nk) STN_ISSUE(kt + NSTAGE - 1);
+        const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
+        const unsigned char* sb = sa + BM_ * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KS / 16; ++ks) {
+            const int chunk = ks * 2 + lh;
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int row = (wm * TM + mi) * 32 + lr;
+                a[mi] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((chunk ^ swz(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int row = (wn * TN + ni) * 32 + lr;
+                b[ni] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((chunk ^ swz(row)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+#undef STN_ISSUE
+
+    // ---- epilogue: TM passes over [WM*32][BN] fp32 slabs --------------------------------------------------
+    // A thread keeps ONE 8-column group for the whole epilogue (NTHR is a multiple of BN/8), so bias / layer-scale
+    // are loaded once, and the per-pass loop is fully unrolled with its global loads (residual) issued up front.
+    float* S = reinterpret_cast<float*>(smem);
+    constexpr int CG = BN_ / 8;                 // 8-column groups per row
+    constexpr int ROWS_PER_IT = NTHR / CG;      // slab rows covered by one sweep of the workgroup
+    constexpr int ITER = (WM * 32) / ROWS_PER_IT;
+    static_assert(NTHR % CG == 0 && (WM * 32) % ROWS_PER_IT == 0, "epilogue thread map");
+    const int half = lane >> 5, cl = lane & 31;
+    const int c8 = tid % CG, rbase = tid / CG;
+    const int n = n0 + c8 * 8;
+    const bool ncol_ok = n < N;
+    float bias[8], gam[8];
+    {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, g0 = make_float4(1.f, 1.f, 1.f, 1.f), g1 = g0;
+        if (ncol_ok && e.bias) { b0 = *reinterpret_cast<const float4*>(e.bias + n); b1 = *reinterpret_cast<const float4*>(e.bias + n + 4); }
+        if (MODE == EPI_RESID && ncol_ok && e.gamma) { g0 = *reinterpret_cast<const float4*>(e.gamma + n); g1 = *reinterpret_cast<const float4*>(e.gamma + n + 4); }
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+        gam[0] = g0.x; gam[1] = g0.y; gam[2] = g0.z; gam[3] = g0.w; gam[4] = g1.x; gam[5] = g1.y; gam[6] = g1.z; gam[7] = g1.w;
+    }
+    const bool to_bf16 = e.out_dtype == BF16;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        // residual rows of this pass: issue the loads before the LDS hand-off so their latency hides behind it
+        float4 r0[ITER], r1[ITER];
+        bool ok[ITER];
+        float keep[ITER];
+        size_t off[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int srow = rbase + it * ROWS_PER_IT;
+            const int m = m0 + ((srow >> 5) * TM + mi) * 32 + (srow & 31);
+            ok[it] = ncol_ok && m < M;
+            keep[it] = 1.f;
+            off[it] = (size_t)m * e.ldo + n;
+            if (ok[it] && e.len) { const int b = m / e.L; if (m - b * e.L >= e.len[b]) keep[it] = 0.f; }
+            if (MODE == EPI_RESID) {
+                r0[it] = make_float4(0.f, 0.f, 0.f, 0.f); r1[it] = r0[it];
+                if (ok[it]) { r0[it] = *reinterpret_cast<const float4*>(e.resid + off[it]); r1[it] = *reinterpret_cast<const float4*>(e.resid + off[it] + 4); }
+            }
+        }
+        __syncthreads();  // ring (pass 0) or previous slab (later passes) fully consumed
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int srow = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                S[srow * BN_ + (wn * TN + ni) * 32 + cl] = acc[mi][ni][i];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int srow = rbase + it * ROWS_PER_IT;
+            const float4 v0 = *reinterpret_cast<const float4*>(S + srow * BN_ + c8 * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(S + srow * BN_ + c8 * 8 + 4);
+            if (!ok[it]) continue;
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (MODE == EPI_STORE) {
+                act8(v, bias, e.act, to_bf16, keep[it]);
+                if (to_bf16) {
+                    uint4 pk;
+                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    pk.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                    pk.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + off[it]) = pk;
+                } else {
+                    float* op = reinterpret_cast<float*>(e.out) + off[it];
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {  // EPI_RESID
+                const float r[8] = {r0[it].x, r0[it].y, r0[it].z, r0[it].w, r1[it].x, r1[it].y, r1[it].z, r1[it].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j])) * keep[it];
+                float* rp = e.resid + off[it];
+                *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(rp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+}
+
+template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS>
+static void launch_tiled(hipStream_t s, const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
+                         const Epilogue& e) {
+    constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_bf16_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A,
+                       lda, W, ldw, M, N, K, tiles_n, ntiles, e);
+}
+
+// tile-shape selection for the vectorised bf16 path; STN_GEMM_CFG=<n> forces one (experiments)
+static int g_gemm_cfg = -2;
+template <int MODE>
+static bool launch_tiled_auto(hipStream_t s, const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
+                              const Epilogue& e) {
+    if (g_gemm_cfg == -2) { const char* c = getenv("STN_GEMM_CFG"); g_gemm_cfg = c ? atoi(c) : -1; }
+    int cfg = g_gemm_cfg;
+    if (cfg < 0) {
+        // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 256x256 tile halves the operand bytes
+        // per FLOP and wins whenever it still yields ~a full wave of workgroups (1 per CU); otherwise the 128x128 ring
+        // (2 workgroups per CU) keeps more CUs busy.
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        if (N >= 256 && t256 >= 200) cfg = 1;
+        else if (K % 64 == 0) cfg = 8;  // 128x128, 8 waves, 128-B rows per stage (full cache lines per DMA row segment)
+        else return false;
+    }
+    if (cfg >= 5 && K % 64) return false;
+    switch (cfg) {
+        case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 2: launch_tiled<MODE, 256, 128, 4, 2, 5, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 3: launch_tiled<MODE, 128, 128, 2, 2, 8, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 4: launch_tiled<MODE, 128, 256, 2, 4, 5, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 5: launch_tiled<MODE, 128, 128, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 6: launch_tiled<MODE, 128, 128, 2, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 7: launch_tiled<MODE, 256, 128, 4, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 8: launch_tiled<MODE, 128, 128, 2, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
+        default: return false;
+    }
+}
+
 void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                  const Epilogue& e) {
     if (M <= 0 || N <= 0) return;
@@ -482,7 +771,7 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     const bool ring = dtype == BF16 && K % RK == 0;
     const void* optr = e.mode == EPI_RESID ? static_cast<const void*>(e.resid) : e.out;
     const bool vec = ring && e.mode <= EPI_RESID && N % 8 == 0 && e.ldo % 8 == 0 && !(reinterpret_cast<uintptr_t>(optr) & 15) &&
-                     (!e.bias || !(reinterpret_cast<uintptr_t>(e.bias) & 3));
+                     (!e.bias || !(reinterpret_cast<uintptr_t>(e.bias) & 15)) && (!e.gamma || !(reinterpret_cast<uintptr_t>(e.gamma) & 15));
 #define STN_LAUNCH(MODE)                                                                                         \
     if (ring && vec)                                                                                             \
         hipLaunchKernelGGL((gemm_bf16_ring_kernel<MODE, true>), dim3(ntiles), dim3(NT), 0, s,                    \
@@ -496,6 +785,12 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     else                                                                                                         \
         hipLaunchKernelGGL(gemm_f32_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const float*>(A),     \
                            lda, static_cast<const float*>(W), ldw, M, N, K, tiles_n, ntiles, e);
+    if (ring && vec && e.mode == EPI_STORE &&
+        launch_tiled_auto<EPI_STORE>(s, static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, e))
+        return;
+    if (ring && vec && e.mode == EPI_RESID &&
+        launch_tiled_auto<EPI_RESID>(s, static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, e))
+        return;
     switch (e.mode) {
         case EPI_STORE: STN_LAUNCH(EPI_STORE) break;
         case EPI_RESID: STN_LAUNCH(EPI_RESID) break;

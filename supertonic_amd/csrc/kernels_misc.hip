@@ -115,6 +115,105 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dwconv + LayerNorm, fast path: compile-time tap count K, R frames per wavefront, C <= 512.
+// Every tap load of every frame is issued before the first FMA (out-of-range taps load a clamped in-range
+// frame and are zeroed by a select), so a wave has R*K independent 16-B loads in flight per channel slot
+// instead of one dependent load per tap; the tap weights are loaded once and shared by the R frames.
+// ---------------------------------------------------------------------------------------------
+template <typename OutT, int K, int R>
+__global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restrict__ x, int64_t M, int L, int C,
+                                                           const float* __restrict__ w_t, const float* __restrict__ bias,
+                                                           int dil, const float* __restrict__ g,
+                                                           const float* __restrict__ bt, float eps, OutT* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (r0 >= M) return;  // wave-uniform
+    const int C4 = C >> 2;
+    constexpr int HALF = (K - 1) / 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* w4 = reinterpret_cast<const float4*>(w_t);
+    const float4* b4 = reinterpret_cast<const float4*>(bias);
+    int tpos[R];
+    int64_t base[R];
+    bool rowok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = r0 + r < M ? r0 + r : M - 1;
+        rowok[r] = r0 + r < M;
+        tpos[r] = (int)(row % L);
+        base[r] = row - tpos[r];
+    }
+    float4 h[R][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c4 = lane + 64 * i;
+        const bool act = c4 < C4;
+        const int cc = act ? c4 : 0;
+        float4 xv[R][K];
+        float4 wv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) wv[j] = w4[(int64_t)j * C4 + cc];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int tt = tpos[r] + (j - HALF) * dil;
+                const int tc = tt < 0 ? 0 : (tt >= L ? L - 1 : tt);
+                xv[r][j] = x4[(base[r] + tc) * C4 + cc];
+            }
+        const float4 bv = b4[cc];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float4 a = bv;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int tt = tpos[r] + (j - HALF) * dil;
+                const float keep = (tt >= 0 && tt < L) ? 1.f : 0.f;
+                a.x = fmaf(wv[j].x * keep, xv[r][j].x, a.x); a.y = fmaf(wv[j].y * keep, xv[r][j].y, a.y);
+                a.z = fmaf(wv[j].z * keep, xv[r][j].z, a.z); a.w = fmaf(wv[j].w * keep, xv[r][j].w, a.w);
+            }
+            h[r][i] = act ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* bt4 = reinterpret_cast<const float4*>(bt);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = (h[r][0].x + h[r][0].y) + (h[r][0].z + h[r][0].w) + (h[r][1].x + h[r][1].y) + (h[r][1].z + h[r][1].w);
+        const float mean = wave_sum(s) / (float)C;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane + 64 * i < C4) {
+                const float dx = h[r][i].x - mean, dy = h[r][i].y - mean, dz = h[r][i].z - mean, dw = h[r][i].w - mean;
+                v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+        if (!rowok[r]) continue;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < C4) {
+                const float4 gg = g4[c4], bb = bt4[c4];
+                store4(y + (r0 + r) * C + c4 * 4, (h[r][i].x - mean) * rstd * gg.x + bb.x, (h[r][i].y - mean) * rstd * gg.y + bb.y,
+                       (h[r][i].z - mean) * rstd * gg.z + bb.z, (h[r][i].w - mean) * rstd * gg.w + bb.w);
+            }
+        }
+    }
+}
+
+template <typename OutT>
+static bool launch_dwconv_ln_v2(hipStream_t s, const float* x, int64_t M, int L, int C, const float* w_t, const float* bias,
+                                int k, int dil, const float* g, const float* b, float eps, OutT* y) {
+    constexpr int R = 2;
+    if (C > 512 || (k != 5 && k != 7)) return false;
+    const dim3 grid((unsigned)((M + 4 * R - 1) / (4 * R)));
+    if (k == 5) hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 5, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y);
+    else hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 7, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y);
+    return true;
+}
+
 static void check_ln_shape(int C) {
     if (C % 4 || C > 4 * 64 * LN_NI) { fprintf(stderr, "stn: LayerNorm width %d unsupported (C %% 4 == 0, C <= 1024)\n", C); abort(); }
 }
@@ -124,6 +223,9 @@ void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L
     check_ln_shape(C);
     const int64_t M = (int64_t)B * L;
     if (M == 0) return;
+    if (out_dtype == BF16 ? launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y))
+                          : launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y)))
+        return;
     const dim3 grid((unsigned)((M + 3) / 4));
     if (out_dtype == BF16)
         hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
