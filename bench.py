@@ -136,8 +136,15 @@ def main():
             ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4))
         roof.update(kernel=dominant, avg_launch_us=round(avg_ms * 1e3, 2), launches_timed=st["launches"],
-                    algorithmic_flops_per_launch=flops_per_launch, algorithmic_bytes_per_launch=bytes_per_launch,
-                    traffic=_pmc_traffic(dominant))
+                    algorithmic_flops_per_launch=flops_per_launch, algorithmic_bytes_per_launch=bytes_per_launch)
+        pmc = _pmc_traffic(dominant)
+        roof["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
+        if pmc:
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+            if "rocprof_avg_us" in pmc:
+                roof["rocprof_avg_us"] = round(pmc["rocprof_avg_us"], 2)
+                roof["timing_note"] = ("avg_launch_us is a HIP-event span on the engine's stream (includes the ~2-5 us dispatch boundary); "
+                                       "rocprof_avg_us is the kernel's own duration from the committed kernel trace")
 
     # ---- p50 per-utterance latency: completion time of the batch that contains the utterance ---------------------
     lat = []

@@ -511,8 +511,29 @@ Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const
     return c;
 }
 
+// sinusoid(t * scale) -> Linear -> SiLU -> Linear -> per-block Linear, for `rows` independent (current, total) pairs
+float* Engine::ve_time_cond_dev(int rows, const float* total_step, const float* current_step) {
+    stage_ = "ve";
+    const stn_arch& a = a_;
+    const int C = a.ve_dim, nb = a.ve_main_blocks;
+    float* tb = f32_alloc((int64_t)rows * nb * C);  // stays allocated for the caller
+    const Arena::Mark mk = ar_.mark();
+    float* te = f32_alloc((int64_t)rows * a.ve_time_dim);
+    launch_time_embed(s_, current_step, total_step, rows, a.ve_time_dim, a.time_scale, te);
+    float* t1 = f32_alloc((int64_t)rows * C);
+    Epilogue et1; et1.mode = EPI_STORE; et1.act = ACT_SILU; et1.out_dtype = F32; et1.out = t1; et1.ldo = C;
+    gemm("gemm_small_f32", F32, te, a.ve_time_dim, linear("ve.t1"), rows, et1);
+    float* tc = f32_alloc((int64_t)rows * C);
+    Epilogue et2; et2.mode = EPI_STORE; et2.out_dtype = F32; et2.out = tc; et2.ldo = C;
+    gemm("gemm_small_f32", F32, t1, C, linear("ve.t2"), rows, et2);
+    Epilogue et3; et3.mode = EPI_STORE; et3.out_dtype = F32; et3.out = tb; et3.ldo = nb * C;
+    gemm("gemm_small_f32", F32, tc, C, linear("ve.time_all"), rows, et3);
+    ar_.release(mk);  // te/t1/tc are dead once the three GEMMs above have run (stream order)
+    return tb;
+}
+
 void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
-                         const float* total_step, const float* current_step, float* denoised) {
+                         const float* total_step, const float* current_step, float* denoised, const float* tb) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, D = a.latent_dim * a.chunk_compress_factor, nb = a.ve_main_blocks, H = a.ve_heads;
@@ -524,18 +545,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     float* x = f32_alloc(M * C);
     Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = x; ein.ldo = C; ein.len = llen; ein.L = L;
     gemm("gemm_in", dt_, z, D, linear("ve.in"), (int)M, ein);
-    // time conditioning (fp32, tiny)
-    float* te = f32_alloc((int64_t)B * a.ve_time_dim);
-    launch_time_embed(s_, current_step, total_step, B, a.ve_time_dim, a.time_scale, te);
-    float* t1 = f32_alloc((int64_t)B * C);
-    Epilogue et1; et1.mode = EPI_STORE; et1.act = ACT_SILU; et1.out_dtype = F32; et1.out = t1; et1.ldo = C;
-    gemm("gemm_small_f32", F32, te, a.ve_time_dim, linear("ve.t1"), B, et1);
-    float* tc = f32_alloc((int64_t)B * C);
-    Epilogue et2; et2.mode = EPI_STORE; et2.out_dtype = F32; et2.out = tc; et2.ldo = C;
-    gemm("gemm_small_f32", F32, t1, C, linear("ve.t2"), B, et2);
-    float* tb = f32_alloc((int64_t)B * nb * C);
-    Epilogue et3; et3.mode = EPI_STORE; et3.out_dtype = F32; et3.out = tb; et3.ldo = nb * C;
-    gemm("gemm_small_f32", F32, tc, C, linear("ve.time_all"), B, et3);
+    if (!tb) tb = ve_time_cond_dev(B, total_step, current_step);
 
     auto cross = [&](const std::string& p, const void* kv_all, int blk, int Lk, const int* klen, int rope_mode) {
         // q from x, K/V precomputed (columns blk*2C .. of kv_all, row stride nb*2C)
@@ -816,11 +826,17 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     }
     // 4. Euler loop: step-invariant K/V once, then total_step estimator passes
     VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl);
-    launch_fill(s_, b.steps, B, (float)total_step);
+    // step counters for every Euler step at once: rows [st*B + b] = (total_step, st); one batched time-conditioning pass
+    float* tot_all = f32_alloc((int64_t)total_step * B);
+    float* cur_all = f32_alloc((int64_t)total_step * B);
+    launch_fill(s_, tot_all, total_step * B, (float)total_step);
+    for (int st = 0; st < total_step; ++st) launch_fill(s_, cur_all + (size_t)st * B, B, (float)st);
+    const float* tb_all = ve_time_cond_dev(total_step * B, tot_all, cur_all);
+    const size_t tb_stride = (size_t)B * a.ve_main_blocks * a.ve_dim;
     int cur = 0;
     for (int st = 0; st < total_step; ++st) {
-        launch_fill(s_, b.steps + B, B, (float)st);
-        ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, b.steps, b.steps + B, b.xt[cur ^ 1]);
+        ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, tot_all + (size_t)st * B, cur_all + (size_t)st * B, b.xt[cur ^ 1],
+                    tb_all + (size_t)st * tb_stride);
         cur ^= 1;
     }
     final_xt_ = cur;

@@ -82,8 +82,11 @@ class Engine {
     void text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl, void* rows);
     struct VeCtx { void* text_kv = nullptr; void* style_kv = nullptr; int Lt = 0; };  // step-invariant K/V
     VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl);
+    // time conditioning of `rows` (= B x steps) (current, total) pairs -> tb [rows][main_blocks * C] (fp32, arena)
+    float* ve_time_cond_dev(int rows, const float* total_step, const float* current_step);
+    // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
-                     const float* total_step, const float* current_step, float* denoised);
+                     const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr);
     void vocoder_dev(int B, int L, const float* latent, float* wav);
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
