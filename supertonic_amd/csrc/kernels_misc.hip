@@ -313,20 +313,24 @@ void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void*
     else hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, s, in, n, static_cast<float*>(out));
 }
 
-__global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, int ldv, int L, int C, int64_t n,
+__global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, int ldv, int L, int C4, int64_t n4,
                                   const int* __restrict__ len) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    const int64_t r = i / C;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B*L][C/4]
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    const int64_t r = i / C4;
     const int t = (int)(r % L);
     const int b = (int)(r / L);
-    if (!len || t < len[b]) x[i] += v[(int64_t)b * ldv + c];
+    if (len && t >= len[b]) return;
+    float4* xp = reinterpret_cast<float4*>(x) + i;
+    const float4 a = *xp, d = *reinterpret_cast<const float4*>(v + (int64_t)b * ldv + c4 * 4);
+    *xp = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
 }
 void launch_add_rowvec(hipStream_t s, float* x, const float* v, int ldv, int B, int L, int C, const int* len) {
-    const int64_t n = (int64_t)B * L * C;
-    if (n == 0) return;
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v, ldv, L, C, n, len);
+    const int64_t n4 = (int64_t)B * L * (C / 4);
+    if (n4 == 0) return;
+    if (C % 4 || ldv % 4) { fprintf(stderr, "stn: add_rowvec needs C %% 4 == 0\n"); abort(); }
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, v, ldv, L, C / 4, n4, len);
 }
 
 __global__ void time_embed_kernel(const float* __restrict__ cur, const float* __restrict__ tot, int dim, float scale,

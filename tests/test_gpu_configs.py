@@ -1,0 +1,113 @@
+"""Parity on the shapes of BASELINE.json's other configs, full 66 M stack, through the C ABI vs the CPU oracle:
+  C4  mixed-length utterances (4..48 words) in one ragged batch, sharded as on 8 GPUs
+  C5  multilingual batch (en/ko/es/pt/fr through the C++ text frontend: Hangul jamo + Latin decomposition) with an
+      inference-steps sweep
+Sizes are kept small enough for the oracle to finish in seconds; the full-size runs are property-checked instead
+(finite, exact zero-masking, sharding invariance)."""
+import numpy as np
+import pytest
+
+from oracle import host_ref
+from oracle.neural_ref import RefModel, randn
+from supertonic_amd import binding, host, workload
+from supertonic_amd.arch import default_arch
+from supertonic_amd.dist import shard_by_length
+from gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return RefModel(default_arch(), 7)
+
+
+@pytest.fixture(scope="module")
+def eng_bf16():
+    e = binding.Engine(0, "bf16")
+    e.load_synthetic(default_arch(), 7)
+    return e
+
+
+@pytest.fixture(scope="module")
+def eng_f32():
+    e = binding.Engine(0, "f32")
+    e.load_synthetic(default_arch(), 7)
+    return e
+
+
+def _prep(texts, langs, ids):
+    a = default_arch()
+    up = host.UnicodeProcessor(host.synthetic_indexer())
+    tid, mask = up(texts, langs)
+    sttl, sdp = workload.synthetic_styles(a, ids)
+    return tid, mask, sttl, sdp
+
+
+def test_c4_mixed_lengths_ragged_batch(ref, eng_f32, eng_bf16):
+    texts = workload.utterances(6, min_words=4, max_words=48, seed=99)
+    tid, mask, sttl, sdp = _prep(texts, ["en"] * 6, np.arange(6))
+    durs = workload.forced_durations(texts)
+    nz = {}
+
+    def nf(B, D, L):
+        nz["x"] = randn(1234, B, D, L, np.arange(6))
+        return nz["x"]
+
+    ref_wav, ref_dur = ref.synthesize(tid, mask, sttl, sdp, 3, 1.05, nf, duration_override=durs)
+    for eng, tmax, trms in ((eng_f32, 2e-3, 5e-4), (eng_bf16, 3e-1, 5e-2)):
+        wav, dur = eng.synthesize(tid, mask, sttl, sdp, 3, 1.05, noise=nz["x"], duration_override=durs)
+        np.testing.assert_allclose(dur, ref_dur, rtol=1e-6)
+        mx, rms = rel_err(wav, ref_wav)
+        assert mx < tmax and rms < trms, (mx, rms)
+        # latent beyond each utterance's own length is exactly zero (masked stages never leak into padding)
+        lat = eng.batch_fetch_latent()
+        _, L, lens = host.latent_geometry(dur, 44100, 512, 6, 24)
+        for b in range(6):
+            assert np.all(lat[b, :, lens[b]:] == 0) and np.abs(lat[b, :, :lens[b]]).min() >= 0
+
+
+def test_c5_multilingual_steps_sweep(ref, eng_bf16):
+    texts = ["Good morning to everyone here.", "안녕하세요 반갑습니다", "¿Cómo estás? Mañana será mejor", "Olá, você está bem? Ação",
+             "Ça va très bien, merci à vous"]
+    langs = ["en", "ko", "es", "pt", "fr"]
+    tid, mask, sttl, sdp = _prep(texts, langs, np.arange(5))
+    # the Korean utterance is tokenised as jamo, the accented ones as base + combining mark (cpp/helper.cpp:272-300)
+    rids, rmask = host_ref.unicode_processor_call(host.synthetic_indexer().tolist(), texts, langs)
+    assert np.array_equal(tid, rids) and np.array_equal(mask, rmask)
+    durs = np.full(5, 1.2, np.float32)
+    for steps in (2, 5, 8):
+        nz = {}
+
+        def nf(B, D, L):
+            nz["x"] = randn(7, B, D, L)
+            return nz["x"]
+
+        ref_wav, _ = ref.synthesize(tid, mask, sttl, sdp, steps, 1.0, nf, duration_override=durs)
+        wav, _ = eng_bf16.synthesize(tid, mask, sttl, sdp, steps, 1.0, noise=nz["x"], duration_override=durs)
+        mx, rms = rel_err(wav, ref_wav)
+        assert rms < 5e-2 and mx < 3e-1, (steps, mx, rms)  # bf16 error does not blow up with more Euler steps
+
+
+def test_c4_full_size_sharding_invariance(eng_bf16):
+    """128 of the 1024 mixed-length utterances exactly as rank 3 of 8 would get them; a few are re-synthesized
+    in a different batch composition and must give the same latent (masked stages, utterance-keyed noise)."""
+    texts_all = workload.utterances(1024, min_words=4, max_words=48, seed=1234)
+    shards = shard_by_length([len(t) for t in texts_all], 8)
+    mine = shards[3]
+    texts = [texts_all[i] for i in mine]
+    tid, mask, sttl, sdp = _prep(texts, ["en"] * len(texts), mine)
+    durs = workload.forced_durations(texts)
+    wav, dur = eng_bf16.synthesize(tid, mask, sttl, sdp, 5, 1.05, duration_override=durs, noise_seed=1234, utt_ids=mine)
+    assert wav.shape[0] == 128 and np.all(np.isfinite(wav))
+    lat = eng_bf16.batch_fetch_latent()
+    _, L, lens = host.latent_geometry(dur, 44100, 512, 6, 24)
+    sub = [5, 64, 127]
+    t2 = [texts[i] for i in sub]
+    tid2, mask2, sttl2, sdp2 = _prep(t2, ["en"] * 3, mine[sub])
+    eng_bf16.synthesize(tid2, mask2, sttl2, sdp2, 5, 1.05, duration_override=durs[sub], noise_seed=1234, utt_ids=mine[sub])
+    lat2 = eng_bf16.batch_fetch_latent()
+    for j, i in enumerate(sub):
+        n = lens[i]
+        mx, _ = rel_err(lat2[j, :, :n], lat[i, :, :n])
+        assert mx < 2e-2, (i, mx)  # different tile shapes / summation orders in bf16, same math
