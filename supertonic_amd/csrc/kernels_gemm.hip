@@ -738,8 +738,11 @@ static bool launch_tiled_auto(hipStream_t s, const uint16_t* A, int lda, const u
         // per FLOP and wins whenever it still yields ~a full wave of workgroups (1 per CU); otherwise the 128x128 ring
         // (2 workgroups per CU) keeps more CUs busy.
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-        if (N >= 256 && t256 >= 200) cfg = 1;
-        else if (K % 64 == 0) cfg = 8;  // 128x128, 8 waves, 128-B rows per stage (full cache lines per DMA row segment)
+        if (N >= 256 && t256 >= 200) {
+            if (t256 < 512) cfg = 11;                      // one round of tiles: 16 waves shorten the per-tile critical path
+            else if (K <= 512 && t256 >= 1024) cfg = 10;   // short K, many tiles: 2 WGs/CU overlap epilogue with main loop
+            else cfg = 1;
+        } else if (K % 64 == 0) cfg = 8;  // 128x128, 8 waves, 128-B rows per stage (full cache lines per DMA row segment)
         else return false;
     }
     if (cfg >= 5 && K % 64) return false;
@@ -752,6 +755,9 @@ static bool launch_tiled_auto(hipStream_t s, const uint16_t* A, int lda, const u
         case 6: launch_tiled<MODE, 128, 128, 2, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
         case 7: launch_tiled<MODE, 256, 128, 4, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
         case 8: launch_tiled<MODE, 128, 128, 2, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
+        case 9: launch_tiled<MODE, 128, 256, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;   // 72 KiB: 2 WGs / CU
+        case 10: launch_tiled<MODE, 256, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB: 2 WGs / CU
+        case 11: launch_tiled<MODE, 256, 256, 4, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 16 waves
         default: return false;
     }
 }
