@@ -253,7 +253,15 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
     decl_ln("te.out_ln", a.te_dim);
     decl_linear("te.proj", a.te_out_dim, a.te_dim, 1.f, false);
     // vector estimator
-    decl_linear("ve.in", a.ve_dim, D, 1.f, false);
+    decl_linear("ve.in", a.ve_dim, D, 1.f, true);
+    {   // K of the input projection padded to a multiple of 64 with zero columns so it runs on the LDS-DMA GEMM path
+        const int Dp = (D + 63) / 64 * 64;
+        const std::vector<float>& w = host.at("ve.in.w");
+        std::vector<float> wp((size_t)a.ve_dim * Dp, 0.f);
+        for (int n = 0; n < a.ve_dim; ++n) std::copy(w.begin() + (size_t)n * D, w.begin() + (size_t)(n + 1) * D, wp.begin() + (size_t)n * Dp);
+        upload("ve.in_pad.w", wp, a.ve_dim, Dp, true);
+        upload("ve.in_pad.b", host.at("ve.in.b"), 1, a.ve_dim, false);
+    }
     decl_linear("ve.t1", a.ve_dim, a.ve_time_dim, 1.f, false);
     decl_linear("ve.t2", a.ve_dim, a.ve_dim, 1.f, false);
     std::vector<std::string> time_parts, text_k, style_k;
@@ -540,11 +548,12 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     const int64_t M = (int64_t)B * L;
     const size_t esz = dt_ == BF16 ? 2 : 4;
     const Arena::Mark mk = ar_.mark();
-    void* z = act_alloc(M * D);
-    launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z);
+    const int Dp = (D + 63) / 64 * 64;
+    void* z = act_alloc(M * Dp);
+    launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z, Dp);
     float* x = f32_alloc(M * C);
     Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = x; ein.ldo = C; ein.len = llen; ein.L = L;
-    gemm("gemm_in", dt_, z, D, linear("ve.in"), (int)M, ein);
+    gemm("gemm_in", dt_, z, Dp, linear("ve.in_pad"), (int)M, ein);
     if (!tb) tb = ve_time_cond_dev(B, total_step, current_step);
 
     auto cross = [&](const std::string& p, const void* kv_all, int blk, int Lk, const int* klen, int rope_mode) {
@@ -586,8 +595,11 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     // Euler update fused into the output projection; dt[b] = 1 / total_step[b]
     float* dtv = f32_alloc(B);
     launch_reciprocal(s_, total_step, B, dtv);
-    Epilogue eo; eo.mode = EPI_EULER_T; eo.out = denoised; eo.aux = noisy; eo.row_scale = dtv; eo.len = llen; eo.L = L;
-    gemm("gemm_out_euler", dt_, xn, C, linear("ve.out"), (int)M, eo);
+    // output projection on the vector-epilogue GEMM path, then the Euler update fused with the [B*L][D] -> [B][D][L] transpose
+    float* vel = f32_alloc(M * D);
+    Epilogue eo; eo.mode = EPI_STORE; eo.out_dtype = F32; eo.out = vel; eo.ldo = D;
+    gemm("gemm_out", dt_, xn, C, linear("ve.out"), (int)M, eo);
+    launch_euler_ncl(s_, noisy, vel, dtv, llen, B, D, L, denoised);
     ar_.release(mk);
 }
 

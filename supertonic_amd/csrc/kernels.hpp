@@ -58,8 +58,10 @@ void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab
                   float* x);
 // prefix mask [B][L] (float) -> len[B] (count of entries > 0.5)
 void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len);
-// [B][C][L] fp32 -> rows [B*L][C] act
-void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out);
+// [B][C][L] fp32 -> rows [B*L][ld_out] act (columns C..ld_out-1 are zero-filled: K padding for the GEMM that follows)
+void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out = 0);
+// Euler update with the [B*L][D] -> [B][D][L] transpose: out[b][d][t] = t < len[b] ? prev[b][d][t] + v[(b*L+t)*D + d] * dt[b] : 0
+void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out);
 // fp32 -> act dtype copy (n elements)
 void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out);
 // x[b*L+t][c] += v[b*ldv + c] for t < len[b]

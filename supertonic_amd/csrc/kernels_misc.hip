@@ -399,21 +399,51 @@ void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len
 }
 
 template <typename OutT>
-__global__ void ncl_to_rows_kernel(const float* __restrict__ in, int C, int L, int64_t n, OutT* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][L][C]
+__global__ void ncl_to_rows_kernel(const float* __restrict__ in, int C, int L, int ldo, int64_t n, OutT* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][L][ldo]
     if (i >= n) return;
-    const int c = (int)(i % C);
-    const int64_t r = i / C;
+    const int c = (int)(i % ldo);
+    const int64_t r = i / ldo;
     const int t = (int)(r % L);
     const int64_t b = r / L;
-    store1(out + i, in[(b * C + c) * L + t]);
+    store1(out + i, c < C ? in[(b * C + c) * L + t] : 0.f);
 }
-void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out) {
-    const int64_t n = (int64_t)B * C * L;
+void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out) {
+    const int ldo = ld_out > 0 ? ld_out : C;
+    const int64_t n = (int64_t)B * ldo * L;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) hipLaunchKernelGGL(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, n, static_cast<uint16_t*>(out));
-    else hipLaunchKernelGGL(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, n, static_cast<float*>(out));
+    if (out_dtype == BF16) hipLaunchKernelGGL(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out));
+    else hipLaunchKernelGGL(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out));
+}
+
+// 32 x 32 LDS tile transpose: reads of v are coalesced along d, writes of out along t
+__global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict__ prev, const float* __restrict__ v,
+                                                        const float* __restrict__ dt, const int* __restrict__ len, int D, int L,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + ty + 8 * k, d = d0 + tx;
+        tile[ty + 8 * k][tx] = (t < L && d < D) ? v[((int64_t)b * L + t) * D + d] : 0.f;
+    }
+    __syncthreads();
+    const int n = len ? len[b] : L;
+    const float scale = dt[b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = d0 + ty + 8 * k, t = t0 + tx;
+        if (d < D && t < L) {
+            const int64_t o = ((int64_t)b * D + d) * L + t;
+            out[o] = t < n ? prev[o] + tile[tx][ty + 8 * k] * scale : 0.f;
+        }
+    }
+}
+void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out) {
+    if (B * D * L == 0) return;
+    hipLaunchKernelGGL(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out);
 }
 
 template <typename OutT>
