@@ -537,42 +537,46 @@ __device__ __forceinline__ void wait_stage(int ahead) {
     wait_vm<0>();
 }
 
-template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_tiled_kernel(const uint16_t* __restrict__ A, int lda,
-                                                                        const uint16_t* __restrict__ W, int ldw, int M,
-                                                                        int N, int K, int tiles_n, int ntiles, Epilogue e) {
-    // KS = K elements per stage: 32 (64-B rows: half a cache line per DMA row segment) or 64 (full 128-B lines)
+template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __restrict__ Av, int lda,
+                                                                   const void* __restrict__ Wv, int ldw, int M, int N, int K,
+                                                                   int tiles_n, int ntiles, Epilogue e) {
+    // ESZ = operand element size: 2 (bf16, v_mfma_f32_32x32x16_bf16) or 4 (fp32, exact v_mfma_f32_32x32x2_f32)
+    // KS  = K elements per stage; rows of KS*ESZ = 64 or 128 bytes (128 = full cache lines per DMA row segment)
     constexpr int NW = WM * WN, NTHR = NW * 64;
     constexpr int TM = BM_ / WM / 32, TN = BN_ / WN / 32;
-    constexpr int ROWB = KS * 2;                 // bytes per LDS row
+    constexpr int ROWB = KS * ESZ;               // bytes per LDS row
     constexpr int RPP = 1024 / ROWB;             // rows per 1-KiB DMA piece (16 or 8)
-    constexpr int CPR = KS / 8;                  // 16-B chunks per row (4 or 8)
+    constexpr int CPR = ROWB / 16;               // 16-B chunks per row (4 or 8)
+    constexpr int EPC = 16 / ESZ;                // elements per 16-B chunk
     constexpr int PA = BM_ / RPP / NW, PW = BN_ / RPP / NW, PER = PA + PW;  // DMA pieces per wave per stage
     constexpr int STAGE = (BM_ + BN_) * ROWB;
-    static_assert(KS == 32 || KS == 64, "KS");
+    static_assert(ROWB == 64 || ROWB == 128, "row bytes");
     static_assert(BM_ % (WM * 32) == 0 && BN_ % (WN * 32) == 0 && (BM_ / RPP) % NW == 0 && (BN_ / RPP) % NW == 0, "tile/wave shape");
     static_assert(NSTAGE * STAGE >= WM * 32 * BN_ * 4, "epilogue slab must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NSTAGE * STAGE bytes, the only LDS object
+    const unsigned char* A = static_cast<const unsigned char*>(Av);
+    const unsigned char* W = static_cast<const unsigned char*>(Wv);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * BM_, n0 = (tile % tiles_n) * BN_;
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A + (size_t)m0 * lda, m0 < M ? (size_t)(M - m0) * lda * 2 : 0);
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W + (size_t)n0 * ldw, n0 < N ? (size_t)(N - n0) * ldw * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A + (size_t)m0 * lda * ESZ, m0 < M ? (size_t)(M - m0) * lda * ESZ : 0);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W + (size_t)n0 * ldw * ESZ, n0 < N ? (size_t)(N - n0) * ldw * ESZ : 0);
     // swizzle of the 16-B slot inside a row: 64-B rows use (row>>2)&3, 128-B rows (row>>1)&7 (see the bank analysis above)
-    auto swz = [](int row) { return KS == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+    auto swz = [](int row) { return ROWB == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
     unsigned offA[PA], offW[PW];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int row = (PA * wave + j) * RPP + lane / CPR;
-        offA[j] = (unsigned)(row * lda + (((lane % CPR) ^ swz(row)) * 8)) * 2u;
+        offA[j] = (unsigned)(row * lda + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
     }
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         const int row = (PW * wave + j) * RPP + lane / CPR;
-        offW[j] = (unsigned)(row * ldw + (((lane % CPR) ^ swz(row)) * 8)) * 2u;
+        offW[j] = (unsigned)(row * ldw + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
     }
     const int nk = K / KS;
 
@@ -605,25 +609,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_tiled_kernel(const uint
         if (kt + NSTAGE - 1 < nk) STN_ISSUE(kt + NSTAGE - 1);
         const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
         const unsigned char* sb = sa + BM_ * ROWB;
+        if constexpr (ESZ == 2) {
 #pragma unroll
-        for (int ks = 0; ks < KS / 16; ++ks) {
-            const int chunk = ks * 2 + lh;
-            bf16x8 a[TM], b[TN];
+            for (int ks = 0; ks < KS / 16; ++ks) {
+                const int chunk = ks * 2 + lh;
+                bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int row = (wm * TM + mi) * 32 + lr;
-                a[mi] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((chunk ^ swz(row)) << 4));
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int row = (wm * TM + mi) * 32 + lr;
+                    a[mi] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((chunk ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int row = (wn * TN + ni) * 32 + lr;
+                    b[ni] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((chunk ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
+        } else {
+            // fp32: lane (row r, half h) feeds A[r][k = 2*ks + h]; one ds_read_b128 covers the lane's k for two MFMA steps
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int row = (wn * TN + ni) * 32 + lr;
-                b[ni] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((chunk ^ swz(row)) << 4));
+            for (int kq = 0; kq < KS / 4; ++kq) {  // 4 consecutive k per 16-B chunk: steps 2kq (k = 4kq + h) and 2kq+1 (k = 4kq + 2 + h)
+                float4 a4[TM], b4[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int row = (wm * TM + mi) * 32 + lr;
+                    a4[mi] = *reinterpret_cast<const float4*>(sa + row * ROWB + ((kq ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int row = (wn * TN + ni) * 32 + lr;
+                    b4[ni] = *reinterpret_cast<const float4*>(sb + row * ROWB + ((kq ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(lh ? a4[mi].y : a4[mi].x, lh ? b4[ni].y : b4[ni].x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(lh ? a4[mi].w : a4[mi].z, lh ? b4[ni].w : b4[ni].z, acc[mi][ni], 0, 0, 0);
+                    }
             }
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
 #undef STN_ISSUE
@@ -711,41 +740,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_tiled_kernel(const uint
     }
 }
 
-template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS>
-static void launch_tiled(hipStream_t s, const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
-                         const Epilogue& e) {
-    constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * 2;
+template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ = 2>
+static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const Epilogue& e) {
+    constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * ESZ;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_bf16_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A,
-                       lda, W, ldw, M, N, K, tiles_n, ntiles, e);
+    hipLaunchKernelGGL((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A, lda,
+                       W, ldw, M, N, K, tiles_n, ntiles, e);
 }
 
-// tile-shape selection for the vectorised bf16 path; STN_GEMM_CFG=<n> forces one (experiments)
+// tile-shape selection for the vectorised-epilogue path; STN_GEMM_CFG=<n> forces one bf16 shape (experiments)
 static int g_gemm_cfg = -2;
 template <int MODE>
-static bool launch_tiled_auto(hipStream_t s, const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
+static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                               const Epilogue& e) {
+    if (dtype == F32) {
+        // fp32 MFMA is 1/16 of the bf16 rate: always compute-bound, tile choice only has to keep the CUs busy
+        if (K % 32) return false;
+        if (M <= 64) launch_tiled<MODE, 64, 64, 2, 2, 4, 32, 4>(s, A, lda, W, ldw, M, N, K, e);
+        else launch_tiled<MODE, 128, 128, 2, 2, 3, 32, 4>(s, A, lda, W, ldw, M, N, K, e);
+        return true;
+    }
     if (g_gemm_cfg == -2) { const char* c = getenv("STN_GEMM_CFG"); g_gemm_cfg = c ? atoi(c) : -1; }
     int cfg = g_gemm_cfg;
     if (cfg < 0) {
-        // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 256x256 tile halves the operand bytes
-        // per FLOP and wins whenever it still yields ~a full wave of workgroups (1 per CU); otherwise the 128x128 ring
-        // (2 workgroups per CU) keeps more CUs busy.
+        // measured on MI355X (tools/gemm_bench.py): the 256x256 tile halves the operand bytes per FLOP and wins whenever
+        // it still yields ~a full wave of workgroups (1 per CU); otherwise the 128x128 tile with 128-byte rows keeps more
+        // CUs busy; tiny M (single utterances) gets 64x64 tiles so that N is spread over more CUs.
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
         if (N >= 256 && t256 >= 200) {
             if (t256 < 512) cfg = 11;                      // one round of tiles: 16 waves shorten the per-tile critical path
             else if (K <= 512 && t256 >= 1024) cfg = 10;   // short K, many tiles: 2 WGs/CU overlap epilogue with main loop
             else cfg = 1;
-        } else if (K % 64 == 0) cfg = 8;  // 128x128, 8 waves, 128-B rows per stage (full cache lines per DMA row segment)
+        } else if (K % 64 == 0) cfg = M <= 64 ? 12 : 8;
         else return false;
     }
-    if (cfg >= 5 && K % 64) return false;
+    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12) && K % 64) return false;
     switch (cfg) {
         case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
         case 2: launch_tiled<MODE, 256, 128, 4, 2, 5, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
@@ -758,6 +793,7 @@ static bool launch_tiled_auto(hipStream_t s, const uint16_t* A, int lda, const u
         case 9: launch_tiled<MODE, 128, 256, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;   // 72 KiB: 2 WGs / CU
         case 10: launch_tiled<MODE, 256, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB: 2 WGs / CU
         case 11: launch_tiled<MODE, 256, 256, 4, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 16 waves
+        case 12: launch_tiled<MODE, 64, 64, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;    // tiny M
         default: return false;
     }
 }
@@ -776,8 +812,13 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     // v2 ring kernel: bf16, K % 32 == 0.  Vectorised epilogue needs 16-B aligned 8-column groups.
     const bool ring = dtype == BF16 && K % RK == 0;
     const void* optr = e.mode == EPI_RESID ? static_cast<const void*>(e.resid) : e.out;
-    const bool vec = ring && e.mode <= EPI_RESID && N % 8 == 0 && e.ldo % 8 == 0 && !(reinterpret_cast<uintptr_t>(optr) & 15) &&
-                     (!e.bias || !(reinterpret_cast<uintptr_t>(e.bias) & 15)) && (!e.gamma || !(reinterpret_cast<uintptr_t>(e.gamma) & 15));
+    const bool vec_ok = e.mode <= EPI_RESID && N % 8 == 0 && e.ldo % 8 == 0 && !(reinterpret_cast<uintptr_t>(optr) & 15) &&
+                        (!e.bias || !(reinterpret_cast<uintptr_t>(e.bias) & 15)) && (!e.gamma || !(reinterpret_cast<uintptr_t>(e.gamma) & 15));
+    const bool vec = ring && vec_ok;
+    if (vec_ok && (ring || dtype == F32)) {
+        if (e.mode == EPI_STORE && launch_tiled_auto<EPI_STORE>(s, dtype, A, lda, W, ldw, M, N, K, e)) return;
+        if (e.mode == EPI_RESID && launch_tiled_auto<EPI_RESID>(s, dtype, A, lda, W, ldw, M, N, K, e)) return;
+    }
 #define STN_LAUNCH(MODE)                                                                                         \
     if (ring && vec)                                                                                             \
         hipLaunchKernelGGL((gemm_bf16_ring_kernel<MODE, true>), dim3(ntiles), dim3(NT), 0, s,                    \
@@ -791,12 +832,6 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     else                                                                                                         \
         hipLaunchKernelGGL(gemm_f32_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const float*>(A),     \
                            lda, static_cast<const float*>(W), ldw, M, N, K, tiles_n, ntiles, e);
-    if (ring && vec && e.mode == EPI_STORE &&
-        launch_tiled_auto<EPI_STORE>(s, static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, e))
-        return;
-    if (ring && vec && e.mode == EPI_RESID &&
-        launch_tiled_auto<EPI_RESID>(s, static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, e))
-        return;
     switch (e.mode) {
         case EPI_STORE: STN_LAUNCH(EPI_STORE) break;
         case EPI_RESID: STN_LAUNCH(EPI_RESID) break;
