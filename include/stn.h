@@ -54,10 +54,17 @@ int stn_create(const stn_config* cfg, stn_handle** out);
 int stn_destroy(stn_handle* h);
 /* message of the last failure on this handle (or of the last failed stn_create when h == NULL) */
 const char* stn_last_error(const stn_handle* h);
-/* tts.json + unicode_indexer.json + the four .onnx files of `onnx_dir` (cpp/helper.cpp:784-823).
- * Reads tts.json; weight import from .onnx initializers is not built yet -> STN_ERR_UNSUPPORTED when
- * the graphs are present, STN_ERR_IO when the directory lacks them. */
+/* The reference's asset directory (cpp/helper.cpp:784-823): tts.json + unicode_indexer.json + the four .onnx graphs.
+ * tts.json fills the descriptor; the weights are the graphs' INITIALIZERS, read by a built-in protobuf reader and bound to
+ * the engine's tensors through `<onnx_dir>/stn_weight_map.json`
+ *   {"arch": {<stn_arch field>: int, ...}, "tensors": {"<engine tensor>": {"file": "vocoder.onnx", "name": "<initializer>",
+ *    "transpose": false}, ...}}
+ * (the real initializer names cannot be known offline, so the manifest is data supplied with the assets).
+ * STN_ERR_IO: a file is missing/unreadable/malformed ("Failed to open ..." as cpp/helper.cpp:805); STN_ERR_UNSUPPORTED: graphs
+ * present but no manifest (the message lists what each graph contains). */
 int stn_load_dir(stn_handle* h, const char* onnx_dir);
+/* '\n'-separated names of every canonical tensor the descriptor implies (what a manifest must map); returns bytes needed */
+int stn_tensor_names(stn_handle* h, const stn_arch* arch, char* out, size_t cap);
 /* descriptor-driven deterministic weights (no asset files needed) */
 int stn_load_synthetic(stn_handle* h, const stn_arch* arch, uint64_t seed);
 int stn_get_arch(const stn_handle* h, stn_arch* out);

@@ -38,6 +38,9 @@ int64_t stn_chunk_text(const char* text, int max_len, char* out, size_t cap, int
 int64_t stn_sanitize_filename(const char* text, int max_len, char* out, size_t cap);
 
 /* 44-byte RIFF header + int16 PCM; returns bytes needed (44 + 2n) */
+/* JSON summary of an .onnx file: ir_version, graph inputs/outputs, op histogram, initializers (name, dtype, dims) */
+int64_t stn_onnx_summary(const char* path, char* out, size_t cap);
+
 int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap);
 int stn_write_wav(const char* path, const float* audio, size_t n, int sample_rate);
 

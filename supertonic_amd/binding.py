@@ -46,6 +46,7 @@ def load():
     L.stn_last_error.restype = ctypes.c_char_p
     L.stn_last_error.argtypes = [vp]
     L.stn_load_dir.argtypes = [vp, ctypes.c_char_p]
+    L.stn_tensor_names.argtypes = [vp, ctypes.POINTER(StnArch), ctypes.c_char_p, ctypes.c_size_t]
     L.stn_load_synthetic.argtypes = [vp, ctypes.POINTER(StnArch), cu64]
     L.stn_get_arch.argtypes = [vp, ctypes.POINTER(StnArch)]
     L.stn_param_count.restype = ctypes.c_int64
@@ -134,6 +135,15 @@ class Engine:
 
     def load_dir(self, onnx_dir: str):
         self._ck(self._lib.stn_load_dir(self._h, onnx_dir.encode()))
+        a = StnArch()
+        self._ck(self._lib.stn_get_arch(self._h, ctypes.byref(a)))
+        self.arch = a
+
+    def tensor_names(self, arch: StnArch):
+        n = self._ck(self._lib.stn_tensor_names(self._h, ctypes.byref(arch), None, 0))
+        buf = ctypes.create_string_buffer(n + 1)
+        self._ck(self._lib.stn_tensor_names(self._h, ctypes.byref(arch), buf, n + 1))
+        return buf.value.decode().split("\n")[:-1]
 
     @property
     def param_count(self):

@@ -7,6 +7,11 @@
 #include <string>
 
 #include "engine.hpp"
+#include "host/json_min.hpp"
+#include "host/onnx_reader.hpp"
+
+#include <map>
+#include <sstream>
 
 struct stn_handle {
     stn::Engine* eng = nullptr;
@@ -67,17 +72,135 @@ const char* stn_last_error(const stn_handle* h) { return h ? h->err.c_str() : g_
 int stn_load_synthetic(stn_handle* h, const stn_arch* arch, uint64_t seed) {
     STN_TRY(h, { need(arch != nullptr, "arch is null"); h->eng->load_synthetic(*arch, seed); })
 }
+extern "C++" {
+namespace {
+std::string slurp_text(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("Failed to open " + path);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+// descriptor fields addressable from tts.json / the manifest's "arch" object
+const std::map<std::string, int32_t stn_arch::*>& arch_fields() {
+    static const std::map<std::string, int32_t stn_arch::*> m = {
+        {"sample_rate", &stn_arch::sample_rate}, {"base_chunk_size", &stn_arch::base_chunk_size},
+        {"chunk_compress_factor", &stn_arch::chunk_compress_factor}, {"latent_dim", &stn_arch::latent_dim},
+        {"vocab_size", &stn_arch::vocab_size}, {"n_style_ttl", &stn_arch::n_style_ttl}, {"d_style_ttl", &stn_arch::d_style_ttl},
+        {"n_style_dp", &stn_arch::n_style_dp}, {"d_style_dp", &stn_arch::d_style_dp},
+        {"te_dim", &stn_arch::te_dim}, {"te_hidden", &stn_arch::te_hidden}, {"te_kernel", &stn_arch::te_kernel},
+        {"te_conv_blocks", &stn_arch::te_conv_blocks}, {"te_attn_blocks", &stn_arch::te_attn_blocks}, {"te_heads", &stn_arch::te_heads},
+        {"te_ffn", &stn_arch::te_ffn}, {"te_style_blocks", &stn_arch::te_style_blocks}, {"te_out_dim", &stn_arch::te_out_dim},
+        {"dp_dim", &stn_arch::dp_dim}, {"dp_hidden", &stn_arch::dp_hidden}, {"dp_kernel", &stn_arch::dp_kernel},
+        {"dp_conv_blocks", &stn_arch::dp_conv_blocks}, {"dp_heads", &stn_arch::dp_heads},
+        {"ve_dim", &stn_arch::ve_dim}, {"ve_hidden", &stn_arch::ve_hidden}, {"ve_kernel", &stn_arch::ve_kernel},
+        {"ve_main_blocks", &stn_arch::ve_main_blocks}, {"ve_dilated", &stn_arch::ve_dilated}, {"ve_tail_blocks", &stn_arch::ve_tail_blocks},
+        {"ve_heads", &stn_arch::ve_heads}, {"ve_time_dim", &stn_arch::ve_time_dim},
+        {"vo_dim", &stn_arch::vo_dim}, {"vo_hidden", &stn_arch::vo_hidden}, {"vo_kernel", &stn_arch::vo_kernel},
+        {"vo_blocks", &stn_arch::vo_blocks}, {"vo_in_kernel", &stn_arch::vo_in_kernel}};
+    return m;
+}
+}  // namespace
+}  // extern "C++"
+
+// Asset directory of the reference (cpp/helper.cpp:784-823): tts.json + unicode_indexer.json + four .onnx graphs, plus
+// `stn_weight_map.json`, a manifest written by whoever holds the real assets:
+//   {"arch": {"ve_dim": 384, ...},                       optional descriptor overrides ("vo_dilations": [..] too)
+//    "tensors": {"vo.blk0.pw1.w": {"file": "vocoder.onnx", "name": "<initializer name>", "transpose": false}, ...}}
+// Every canonical tensor of the descriptor must be mapped; "transpose": true for MatMul weights stored [K][N].
 int stn_load_dir(stn_handle* h, const char* onnx_dir) {
     if (!h) return STN_ERR_INVALID;
     if (!onnx_dir) { h->err = "onnx_dir is null"; return STN_ERR_INVALID; }
+    const std::string dir = onnx_dir;
     static const char* files[] = {"tts.json", "unicode_indexer.json", "duration_predictor.onnx", "text_encoder.onnx",
                                   "vector_estimator.onnx", "vocoder.onnx"};
     for (const char* f : files) {
-        std::ifstream in(std::string(onnx_dir) + "/" + f, std::ios::binary);
-        if (!in.is_open()) { h->err = std::string("Failed to open ") + onnx_dir + "/" + f; return STN_ERR_IO; }
+        std::ifstream in(dir + "/" + f, std::ios::binary);
+        if (!in.is_open()) { h->err = "Failed to open " + dir + "/" + f; return STN_ERR_IO; }
     }
-    h->err = "ONNX initializer import is not built yet (SURVEY.md §8 row f1); use stn_load_synthetic";
-    return STN_ERR_UNSUPPORTED;
+    try {
+        using stn::json::Value;
+        stn_arch a;
+        stn_arch_default(&a);
+        const Value cfg = stn::json::parse(slurp_text(dir + "/tts.json"));
+        // the four fields every host reads (cpp/helper.cpp:811-815) + the style/projection dims of go/helper.go:45-78 when present
+        a.sample_rate = cfg.at("ae").at("sample_rate").as_int();
+        a.base_chunk_size = cfg.at("ae").at("base_chunk_size").as_int();
+        a.chunk_compress_factor = cfg.at("ttl").at("chunk_compress_factor").as_int();
+        a.latent_dim = cfg.at("ttl").at("latent_dim").as_int();
+        auto opt = [](const Value& v, std::initializer_list<const char*> path, int32_t& dst) {
+            const Value* cur = &v;
+            for (const char* k : path) { if (!cur->is_object() || !cur->has(k)) return; cur = &cur->at(k); }
+            if (cur->type == Value::Number) dst = (int32_t)cur->num;
+        };
+        opt(cfg, {"ttl", "style_encoder", "style_token_layer", "n_style"}, a.n_style_ttl);
+        opt(cfg, {"ttl", "style_encoder", "style_token_layer", "style_value_dim"}, a.d_style_ttl);
+        opt(cfg, {"ttl", "text_encoder", "proj_out", "odim"}, a.te_out_dim);
+        opt(cfg, {"dp", "style_encoder", "style_token_layer", "n_style"}, a.n_style_dp);
+        opt(cfg, {"dp", "style_encoder", "style_token_layer", "style_value_dim"}, a.d_style_dp);
+
+        const std::string man_path = dir + "/stn_weight_map.json";
+        std::map<std::string, stn::onnx::Model> models;
+        static const char* graphs[] = {"duration_predictor.onnx", "text_encoder.onnx", "vector_estimator.onnx", "vocoder.onnx"};
+        {
+            std::ifstream probe(man_path);
+            if (!probe.is_open()) {
+                std::ostringstream msg;
+                msg << "no weight manifest (" << man_path << "): the graphs' initializer names cannot be known offline;";
+                for (const char* g : graphs) {
+                    const stn::onnx::Model m = stn::onnx::parse_file(dir + "/" + g);
+                    msg << " " << g << ": " << m.initializers.size() << " initializers, " << m.nodes.size() << " nodes;";
+                }
+                h->err = msg.str();
+                return STN_ERR_UNSUPPORTED;
+            }
+        }
+        const Value man = stn::json::parse(slurp_text(man_path));
+        if (man.has("arch")) {
+            for (const auto& kv : man.at("arch").obj) {
+                if (kv.first == "vo_dilations") {
+                    for (size_t i = 0; i < kv.second.arr.size() && i < STN_MAX_VO_BLOCKS; ++i) a.vo_dilations[i] = kv.second.arr[i].as_int();
+                    continue;
+                }
+                auto it = arch_fields().find(kv.first);
+                if (it == arch_fields().end()) throw std::runtime_error("manifest: unknown arch field \"" + kv.first + "\"");
+                a.*(it->second) = kv.second.as_int();
+            }
+        }
+        for (const char* g : graphs) models.emplace(g, stn::onnx::parse_file(dir + "/" + g));
+        const Value& tmap = man.at("tensors");
+        h->eng->load_tensors(a, [&](const std::string& name, int rows, int cols) {
+            if (!tmap.has(name)) throw std::runtime_error("manifest: no entry for tensor \"" + name + "\"");
+            const Value& ent = tmap.at(name);
+            const std::string file = ent.at("file").str, iname = ent.at("name").str;
+            auto mit = models.find(file);
+            if (mit == models.end()) throw std::runtime_error("manifest: unknown graph file \"" + file + "\" for " + name);
+            const stn::onnx::Tensor* t = mit->second.find(iname);
+            if (!t) throw std::runtime_error(file + ": no initializer named \"" + iname + "\" (for " + name + ")");
+            std::vector<float> v = stn::onnx::to_float(*t);
+            if (v.size() != (size_t)rows * cols)
+                throw std::runtime_error(name + ": initializer " + iname + " has " + std::to_string(v.size()) + " elements, descriptor wants " +
+                                         std::to_string(rows) + "x" + std::to_string(cols));
+            if (ent.has("transpose") && ent.at("transpose").boolean) {  // stored [cols][rows] -> canonical [rows][cols]
+                std::vector<float> w(v.size());
+                for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) w[(size_t)r * cols + c] = v[(size_t)c * rows + r];
+                v.swap(w);
+            }
+            return v;
+        });
+        return STN_OK;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return h->err.rfind("HIP error", 0) == 0 ? STN_ERR_DEVICE : STN_ERR_IO;
+    }
+}
+int stn_tensor_names(stn_handle* h, const stn_arch* arch, char* out, size_t cap) {
+    if (!h || !arch) return STN_ERR_INVALID;
+    try {
+        std::string packed;
+        const auto names = h->eng->tensor_names(*arch);
+        for (const auto& n : names) { packed += n; packed.push_back('\n'); }
+        if (out && cap > packed.size()) std::memcpy(out, packed.c_str(), packed.size() + 1);
+        return (int)packed.size();
+    } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_STATE; }
 }
 int stn_get_arch(const stn_handle* h, stn_arch* out) {
     if (!h || !out) return STN_ERR_INVALID;

@@ -158,10 +158,29 @@ Attn Engine::attn_w(const std::string& p, bool self) {
 }
 
 void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
-    STN_HIP(hipSetDevice(device_));
-    sync();
-    free_weights();
-    a_ = a;
+    load_weights(a, [seed](const std::string& name, int kind, int rows, int cols, float gain) {
+        return synth(seed, name, (Kind)kind, rows, cols, gain); }, nullptr);
+}
+void Engine::load_tensors(const stn_arch& a, const TensorSource& src) {
+    load_weights(a, [&src](const std::string& name, int, int rows, int cols, float) {
+        std::vector<float> v = src(name, rows, cols);
+        if (v.size() != (size_t)rows * cols)
+            throw std::runtime_error("tensor " + name + ": expected " + std::to_string((size_t)rows * cols) + " values, got " + std::to_string(v.size()));
+        return v; }, nullptr);
+}
+std::vector<std::string> Engine::tensor_names(const stn_arch& a) {
+    std::vector<std::string> names;
+    load_weights(a, RawSource(), &names);
+    return names;
+}
+
+void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<std::string>* names_only) {
+    if (!names_only) {
+        STN_HIP(hipSetDevice(device_));
+        sync();
+        free_weights();
+        a_ = a;
+    }
     const int D = a.latent_dim * a.chunk_compress_factor;
     if (a.te_dim % a.te_heads || a.dp_dim % a.dp_heads || a.ve_dim % a.ve_heads)
         throw std::runtime_error("model width must be divisible by the head count");
@@ -169,6 +188,7 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
 
     std::unordered_map<std::string, std::vector<float>> host;  // canonical copies kept for derived tensors
     auto upload = [&](const std::string& name, const std::vector<float>& v, int rows, int cols, bool want_bf16) {
+        if (names_only) return;
         DevTensor t;
         t.rows = rows;
         t.cols = cols;
@@ -185,7 +205,8 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
         w_[name] = t;
     };
     auto decl = [&](const std::string& name, Kind kind, int rows, int cols, float gain, bool matrix, bool keep) {
-        std::vector<float> v = synth(seed, name, kind, rows, cols, gain);
+        if (names_only) { names_only->push_back(name); if (keep) host[name] = std::vector<float>((size_t)rows * cols, 0.f); return; }
+        std::vector<float> v = src(name, (int)kind, rows, cols, gain);
         params_ += (int64_t)v.size();
         upload(name, v, rows, cols, matrix);
         if (keep) host[name] = std::move(v);
@@ -199,8 +220,9 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
         decl(p + ".b", K_LN_B, 1, c, 1.f, false, false);
     };
     auto decl_convnext = [&](const std::string& p, int c, int hid, int k) {
-        std::vector<float> w = synth(seed, p + ".dw.w", K_W, c, k, 1.f);  // canonical [C][k]
-        params_ += (int64_t)w.size();
+        if (names_only) names_only->push_back(p + ".dw.w");
+        std::vector<float> w = names_only ? std::vector<float>((size_t)c * k, 0.f) : src(p + ".dw.w", (int)K_W, c, k, 1.f);  // canonical [C][k]
+        if (!names_only) params_ += (int64_t)w.size();
         std::vector<float> wt((size_t)c * k);                            // stored [k][C]: coalesced per tap
         for (int ch = 0; ch < c; ++ch) for (int j = 0; j < k; ++j) wt[(size_t)j * c + ch] = w[(size_t)ch * k + j];
         upload(p + ".dw.wt", wt, k, c, false);
@@ -285,8 +307,9 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
     // vocoder
     {
         const int ld = a.latent_dim, k = a.vo_in_kernel, C = a.vo_dim;
-        std::vector<float> w = synth(seed, "vo.in.w", K_W, C, ld * k, 1.f);  // canonical [C][ld][k]
-        params_ += (int64_t)w.size();
+        if (names_only) names_only->push_back("vo.in.w");
+        std::vector<float> w = names_only ? std::vector<float>((size_t)C * ld * k, 0.f) : src("vo.in.w", (int)K_W, C, ld * k, 1.f);  // canonical [C][ld][k]
+        if (!names_only) params_ += (int64_t)w.size();
         std::vector<float> wt(w.size());                                     // stored [ld*k][C]
         for (int co = 0; co < C; ++co) for (int i = 0; i < ld * k; ++i) wt[(size_t)i * C + co] = w[(size_t)co * ld * k + i];
         upload("vo.in.wt", wt, ld * k, C, false);
@@ -295,7 +318,7 @@ void Engine::load_synthetic(const stn_arch& a, uint64_t seed) {
     for (int i = 0; i < a.vo_blocks; ++i) decl_convnext(S("vo.blk%d", i), a.vo_dim, a.vo_hidden, a.vo_kernel);
     decl_ln("vo.out_ln", a.vo_dim);
     decl_linear("vo.head", a.base_chunk_size, a.vo_dim, a.head_gain, false);
-    loaded_ = true;
+    if (!names_only) loaded_ = true;
 }
 
 // =================================================================================================

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -65,6 +66,11 @@ class Engine {
     Engine(const Engine&) = delete;
 
     void load_synthetic(const stn_arch& a, uint64_t seed);
+    // canonical tensors by name from any source (ONNX initializers through a manifest, ...): fn(name, rows, cols) must return
+    // rows*cols floats in the canonical layout (Linear [N][K]; depthwise [C][k]; vocoder input conv [Cout][Cin][k]; 1-D as [1][n])
+    using TensorSource = std::function<std::vector<float>(const std::string& name, int rows, int cols)>;
+    void load_tensors(const stn_arch& a, const TensorSource& src);
+    std::vector<std::string> tensor_names(const stn_arch& a);  // every canonical tensor the descriptor implies (no device work)
     bool loaded() const { return loaded_; }
     const stn_arch& arch() const { return a_; }
     int64_t param_count() const { return params_; }
@@ -148,6 +154,8 @@ class Engine {
     ConvNeXt convnext_w(const std::string& prefix);
     Attn attn_w(const std::string& prefix, bool self);
     void free_weights();
+    using RawSource = std::function<std::vector<float>(const std::string& name, int kind, int rows, int cols, float gain)>;
+    void load_weights(const stn_arch& a, const RawSource& src, std::vector<std::string>* names_only);
 
     // building blocks (enqueue on s_)
     size_t act_bytes(int64_t n) const { return (size_t)n * (dt_ == BF16 ? 2 : 4); }

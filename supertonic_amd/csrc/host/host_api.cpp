@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../../include/stn.h"
+#include "onnx_reader.hpp"
 #include "text_frontend.hpp"
 
 static thread_local std::string g_err;
@@ -87,6 +88,14 @@ int64_t stn_sanitize_filename(const char* text, int max_len, char* out, size_t c
         if (!text) throw std::runtime_error("null argument");
         return emit(stn::host::sanitize_filename(text, max_len), out, cap);
     });
+}
+
+int64_t stn_onnx_summary(const char* path, char* out, size_t cap) {
+    const int64_t rc = guarded([&]() -> int64_t {
+        if (!path) throw std::runtime_error("null argument");
+        return emit(stn::onnx::summary_json(stn::onnx::parse_file(path)), out, cap);
+    });
+    return rc < 0 ? STN_ERR_IO : rc;
 }
 
 int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap) {

@@ -25,6 +25,8 @@ def _lib():
         L.stn_chunk_text.argtypes = [c, ctypes.c_int, ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_int)]
         L.stn_sanitize_filename.restype = i64
         L.stn_sanitize_filename.argtypes = [c, ctypes.c_int, ctypes.c_void_p, sz]
+        L.stn_onnx_summary.restype = i64
+        L.stn_onnx_summary.argtypes = [c, ctypes.c_void_p, sz]
         L.stn_wav_encode.restype = i64
         L.stn_wav_encode.argtypes = [ctypes.c_void_p, sz, ctypes.c_int, ctypes.c_void_p, sz]
         L.stn_write_wav.argtypes = [c, ctypes.c_void_p, sz, ctypes.c_int]
@@ -115,6 +117,18 @@ def sanitize_filename(text: str, max_len: int) -> str:
     buf = ctypes.create_string_buffer(n + 1)
     L.stn_sanitize_filename(_enc(text), max_len, buf, n + 1)
     return _dec(buf.raw[:n])
+
+
+def onnx_summary(path: str) -> dict:
+    """What the built-in protobuf reader sees in an .onnx file (inputs, outputs, op histogram, initializers)."""
+    import json
+    L = _lib()
+    n = L.stn_onnx_summary(path.encode(), None, 0)
+    if n < 0:
+        raise OSError(L.stn_host_last_error().decode())
+    buf = ctypes.create_string_buffer(n + 1)
+    L.stn_onnx_summary(path.encode(), buf, n + 1)
+    return json.loads(buf.value.decode())
 
 
 def wav_bytes(audio, sample_rate: int) -> bytes:
