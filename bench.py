@@ -47,8 +47,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # the multi-GPU code path (process group, shared stream, waveform gather); STN_BENCH_FORCE_DIST=1 exercises it at world 1
+    use_dist = world > 1 or os.environ.get("STN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -68,15 +71,20 @@ def main():
 
     eng = binding.Engine(local, args.dtype)
     eng.load_synthetic(arch, 7)
-    if world > 1:
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)  # RCCL gather orders after the engine's kernels
+    side = None
+    if use_dist:
+        # one dedicated (non-default) stream carries the engine's kernels AND the RCCL gather, so the collective is ordered
+        # after the waveform copy without a host sync.  (The default stream's handle is 0 = "engine's own stream".)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+        eng.set_stream(side.cuda_stream)
     eng.batch_upload(ids, mask, sttl, sdp, duration_override=durs, utt_ids=mine)
 
     gather_buf = {}
 
     def step():
         eng.batch_run(args.total_step, args.speed, 1234)
-        if world > 1:
+        if use_dist:
             B, L, W = eng.batch_dims()
             if gather_buf.get("shape") != (B, W):
                 gather_buf["wav"] = torch.empty((B, W), dtype=torch.float32, device=dev)
@@ -86,7 +94,7 @@ def main():
             gather_waveforms(gather_buf["wav"], gather_buf["dur"], dst=0)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         eng.sync()
         torch.cuda.synchronize()
@@ -116,7 +124,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -157,7 +165,7 @@ def main():
     p50 = float(np.median(lat))
 
     audio_per_step_rank = float((durs / np.float32(args.speed)).sum())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([audio_per_step_rank], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         audio_per_step = float(t.item())
@@ -203,7 +211,8 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        eng.sync()
         dist.barrier()
         dist.destroy_process_group()
 

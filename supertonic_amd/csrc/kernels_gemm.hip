@@ -606,31 +606,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     for (int kt = 0; kt < nk; ++kt) {
         wait_stage<PER, NSTAGE - 2>(nk - 1 - kt);
         __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < nk) STN_ISSUE(kt + NSTAGE - 1);
         const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
         const unsigned char* sb = sa + BM_ * ROWB;
         if constexpr (ESZ == 2) {
+            // The K-loop is latency-bound per wave, not bandwidth-bound (PMC: L1->L2 read latency ~420 cycles, MFMA pipe busy
+            // ~30 %): so ALL fragment reads of the stage are issued right behind the barrier, the LDS-DMA refill of the
+            // vacated stage goes out while they are in flight, and the MFMAs then run back to back behind counted lgkmcnt waits.
+            constexpr int NKS = KS / 16;
+            bf16x8 a[NKS][TM], b[NKS][TN];
 #pragma unroll
-            for (int ks = 0; ks < KS / 16; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 const int chunk = ks * 2 + lh;
-                bf16x8 a[TM], b[TN];
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) {
                     const int row = (wm * TM + mi) * 32 + lr;
-                    a[mi] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((chunk ^ swz(row)) << 4));
+                    a[ks][mi] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((chunk ^ swz(row)) << 4));
                 }
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) {
                     const int row = (wn * TN + ni) * 32 + lr;
-                    b[ni] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((chunk ^ swz(row)) << 4));
+                    b[ks][ni] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((chunk ^ swz(row)) << 4));
                 }
+            }
+            if (kt + NSTAGE - 1 < nk) STN_ISSUE(kt + NSTAGE - 1);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mi], b[ks][ni], acc[mi][ni], 0, 0, 0);
         } else {
+            if (kt + NSTAGE - 1 < nk) STN_ISSUE(kt + NSTAGE - 1);
             // fp32: lane (row r, half h) feeds A[r][k = 2*ks + h]; one ds_read_b128 covers the lane's k for two MFMA steps
 #pragma unroll
             for (int kq = 0; kq < KS / 4; ++kq) {  // 4 consecutive k per 16-B chunk: steps 2kq (k = 4kq + h) and 2kq+1 (k = 4kq + 2 + h)
