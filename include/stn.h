@@ -96,6 +96,9 @@ int stn_batch_set_noise(stn_handle* h, const float* noise /*[B,D,L]*/, int L);
 int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_seed);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
 int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);
+/* same, as 16-bit PCM converted on the GPU exactly as writeWavFile does (clamp to [-1,1], *32767, truncation;
+ * cpp/helper.cpp:986-987): half the device->host bytes */
+int stn_batch_fetch_pcm16(stn_handle* h, int16_t* pcm, size_t capacity_samples, float* duration);
 int stn_batch_fetch_latent(stn_handle* h, float* latent /*[B,D,L]*/);
 /* device pointer of the finished waveform [B, L*cs] float32 (valid until the next upload/run) */
 int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr);

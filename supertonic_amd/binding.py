@@ -61,6 +61,7 @@ def load():
     L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
     L.stn_batch_fetch.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
+    L.stn_batch_fetch_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.stn_batch_wav_device_ptr.argtypes = [vp, ctypes.POINTER(vp)]
     L.stn_sync.argtypes = [vp]
     L.stn_set_stream.argtypes = [vp, vp]
@@ -211,6 +212,13 @@ class Engine:
         self._ck(self._lib.stn_batch_fetch(self._h, wav.ctypes.data if want_wav else None, B * W if want_wav else 0,
                                            dur.ctypes.data))
         return wav, dur
+
+    def batch_fetch_pcm16(self):
+        B, L, W = self.batch_dims()
+        pcm = np.empty((B, W), np.int16)
+        dur = np.empty(B, np.float32)
+        self._ck(self._lib.stn_batch_fetch_pcm16(self._h, pcm.ctypes.data, B * W, dur.ctypes.data))
+        return pcm, dur
 
     def batch_fetch_latent(self):
         B, L, _ = self.batch_dims()

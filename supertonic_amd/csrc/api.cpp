@@ -255,6 +255,9 @@ int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len) {
 int stn_batch_fetch(stn_handle* h, float* wav, size_t cap, float* duration) {
     STN_TRY(h, { need(h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch(wav, cap, duration); })
 }
+int stn_batch_fetch_pcm16(stn_handle* h, int16_t* pcm, size_t cap, float* duration) {
+    STN_TRY(h, { need(pcm && h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_pcm16(pcm, cap, duration); })
+}
 int stn_batch_fetch_latent(stn_handle* h, float* latent) {
     STN_TRY(h, { need(latent && h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_latent(latent); })
 }

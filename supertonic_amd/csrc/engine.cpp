@@ -889,6 +889,18 @@ void Engine::batch_fetch(float* wav, size_t wav_capacity, float* duration) {
     sync();
     if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
 }
+void Engine::batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration) {
+    STN_HIP(hipSetDevice(device_));
+    Batch& b = bt_;
+    const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
+    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
+    if (capacity < nw) throw std::runtime_error("pcm buffer too small: need " + std::to_string(nw) + " samples");
+    grow(batch_owned_, b.pcm, b.pcm_cap, nw);
+    launch_f32_to_pcm16(s_, b.wav, (int64_t)nw, b.pcm);
+    STN_HIP(hipMemcpyAsync(pcm, b.pcm, nw * 2, hipMemcpyDeviceToHost, s_));
+    sync();
+    if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
+}
 void Engine::batch_copy_wav_device(float* dst, int64_t dst_stride) {
     Batch& b = bt_;
     const size_t W = (size_t)b.L * a_.base_chunk_size * a_.chunk_compress_factor;

@@ -114,6 +114,7 @@ class Engine {
         float* noise = nullptr; size_t noise_cap = 0;   // injected noise [B,D,L] (optional)
         float* xt[2] = {nullptr, nullptr}; size_t xt_cap = 0;
         float* wav = nullptr; size_t wav_cap = 0;        // [B, L*cs]
+        int16_t* pcm = nullptr; size_t pcm_cap = 0;      // [B, L*cs] int16 (on demand)
         float* steps = nullptr;                          // [2][B]: total_step, current_step
         std::vector<float> h_dur; std::vector<int> h_llen;
     };
@@ -123,6 +124,8 @@ class Engine {
     void batch_run(int total_step, float speed, uint64_t noise_seed);
     const Batch& batch() const { return bt_; }
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
+    // waveform as 16-bit PCM (clamp, *32767, truncate: cpp/helper.cpp:986-987) converted on the GPU: half the D2H bytes
+    void batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration);
     void batch_fetch_latent(float* latent);  // final denoised latent [B,D,L] (tests)
     // device->device: wav rows [B][W] into dst rows of stride dst_stride floats (>= W), on the engine's stream
     void batch_copy_wav_device(float* dst, int64_t dst_stride);

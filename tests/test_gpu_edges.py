@@ -1,0 +1,98 @@
+"""Edge cases of the path on a real MI355X (the reference has no tests; these are the boundaries its host code handles):
+empty text, one-frame latents, maximum-length text, single/50 Euler steps, batch/style mismatches, PCM conversion."""
+import numpy as np
+import pytest
+
+from oracle import host_ref
+from oracle.neural_ref import RefModel, randn
+from supertonic_amd import binding, host, workload
+from supertonic_amd.arch import tiny_arch
+from gpu_util import make_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return RefModel(tiny_arch(), 7)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = binding.Engine(0, "f32")
+    e.load_synthetic(tiny_arch(), 7)
+    return e
+
+
+def _run_both(ref, eng, ids, mask, sttl, sdp, steps, speed, durs, tol=2e-3):
+    nz = {}
+
+    def nf(B, D, L):
+        nz["x"] = randn(5, B, D, L)
+        return nz["x"]
+
+    rw, rd = ref.synthesize(ids, mask, sttl, sdp, steps, speed, nf, duration_override=durs)
+    w, d = eng.synthesize(ids, mask, sttl, sdp, steps, speed, noise=nz["x"], duration_override=durs)
+    assert w.shape == rw.shape
+    np.testing.assert_allclose(d, rd, rtol=1e-6)
+    mx, _ = rel_err(w, rw)
+    assert mx < tol, mx
+    return w, d
+
+
+def test_empty_text_and_ragged_batch(ref, eng):
+    """'' -> '<en></en>' (9 tokens, no period added: cpp/helper.cpp:156) next to a long utterance."""
+    a = tiny_arch()
+    up = host.UnicodeProcessor(host.synthetic_indexer())
+    ids, mask = up(["", "A considerably longer sentence than the empty one."], ["en", "en"])
+    assert mask.sum(axis=(1, 2)).astype(int).tolist() == [9, 59]
+    sttl, sdp = workload.synthetic_styles(a, [0, 1])
+    _run_both(ref, eng, ids, mask, sttl, sdp, 2, 1.05, np.array([0.08, 0.9], np.float32))
+
+
+def test_one_latent_frame_and_single_token(ref, eng):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 1, 1, [1], seed=2)
+    w, d = _run_both(ref, eng, ids, mask, sttl, sdp, 1, 1.0, np.array([0.01], np.float32))  # 441 samples -> L = 1
+    assert w.shape == (1, a.chunk_size)
+
+
+def test_maximum_text_length_and_many_steps(ref, eng):
+    """chunkText caps a chunk at 300 characters (cpp/helper.cpp:698) -> ~310 tokens with tags; total_step up to 50 (service.py:36)."""
+    a = tiny_arch()
+    text = ("abcdefghi " * 30).strip()[:299] + "."
+    ids, mask = host.UnicodeProcessor(host.synthetic_indexer())([text], ["en"])
+    assert ids.shape[1] == 300 + 9
+    sttl, sdp = workload.synthetic_styles(a, [3])
+    _run_both(ref, eng, ids, mask, sttl, sdp, 50, 2.0, np.array([1.0], np.float32), tol=1e-2)
+
+
+def test_style_text_count_mismatch_is_an_error(eng):
+    """cpp/helper.cpp:479-481 throws 'Number of texts must match number of style vectors'; at the C ABI the batch size is a
+    single argument, so the mismatch can only show up as buffers of the wrong size — the host layers check it."""
+    from supertonic_amd import host as H
+    with pytest.raises(ValueError):
+        H.UnicodeProcessor(H.synthetic_indexer())(["a", "b"], ["en"])
+
+
+def test_pcm16_fetch_matches_reference_wav_conversion(eng):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 2, 10, [10, 6], seed=4)
+    wav, dur = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=np.array([0.2, 0.1], np.float32))
+    wav2 = wav * 25.0  # drive part of the signal into clipping
+    pcm, dur2 = eng.batch_fetch_pcm16()
+    ref_pcm = np.frombuffer(host_ref.wav_bytes(wav.ravel(), a.sample_rate)[44:], dtype="<i2").reshape(wav.shape)
+    assert np.array_equal(pcm, ref_pcm) and np.array_equal(dur, dur2)
+    # the host-side encoder (C++) agrees with the oracle on clipped data too
+    assert host.wav_bytes(wav2.ravel(), a.sample_rate) == host_ref.wav_bytes(wav2.ravel(), a.sample_rate)
+
+
+def test_speed_scales_duration_and_length(eng):
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 1, 8, [8], seed=6)
+    _, d1 = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, noise_seed=3)
+    _, L1, _ = eng.batch_dims()
+    _, d2 = eng.synthesize(ids, mask, sttl, sdp, 2, 2.0, noise_seed=3)
+    _, L2, _ = eng.batch_dims()
+    np.testing.assert_allclose(d2 * 2, d1, rtol=1e-6)  # duration /= speed (cpp/helper.cpp:529-531)
+    assert L2 <= (L1 + 1) // 2 + 1
