@@ -94,6 +94,10 @@ int stn_batch_upload(stn_handle* h, int B, int Lt, const int64_t* text_ids, cons
                      const int64_t* utt_ids_or_null);
 int stn_batch_set_noise(stn_handle* h, const float* noise /*[B,D,L]*/, int L);
 int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_seed);
+/* hipGraph replay of the post-duration pipeline (default on): a shape is captured the second time it is run and replayed
+ * afterwards; stn_graph_replays counts replays (tests / diagnostics) */
+int stn_set_graph_mode(stn_handle* h, int on);
+int64_t stn_graph_replays(const stn_handle* h);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
 int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);
 /* same, as 16-bit PCM converted on the GPU exactly as writeWavFile does (clamp to [-1,1], *32767, truncation;

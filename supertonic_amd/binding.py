@@ -58,6 +58,9 @@ def load():
     L.stn_batch_upload.argtypes = [vp, ci, ci, _i64p, _f32p, _f32p, _f32p, vp, vp]
     L.stn_batch_set_noise.argtypes = [vp, _f32p, ci]
     L.stn_batch_run.argtypes = [vp, ci, cf, cu64]
+    L.stn_set_graph_mode.argtypes = [vp, ci]
+    L.stn_graph_replays.restype = ctypes.c_int64
+    L.stn_graph_replays.argtypes = [vp]
     L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
     L.stn_batch_fetch.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
@@ -199,6 +202,13 @@ class Engine:
 
     def batch_run(self, total_step=5, speed=1.05, noise_seed=1234):
         self._ck(self._lib.stn_batch_run(self._h, total_step, speed, noise_seed))
+
+    def set_graph_mode(self, on=True):
+        self._ck(self._lib.stn_set_graph_mode(self._h, int(on)))
+
+    @property
+    def graph_replays(self):
+        return self._lib.stn_graph_replays(self._h)
 
     def batch_dims(self):
         B, L, W = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()

@@ -243,6 +243,8 @@ int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_see
     STN_TRY(h, { need_model(h); need(total_step >= 1, "total_step must be >= 1"); need(speed > 0.f, "speed must be > 0");
                  h->eng->batch_run(total_step, speed, noise_seed); })
 }
+int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_mode(on != 0); }) }
+int64_t stn_graph_replays(const stn_handle* h) { return h ? h->eng->graph_replays() : 0; }
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len) {
     if (!h) return STN_ERR_INVALID;
     const auto& b = h->eng->batch();

@@ -122,6 +122,10 @@ class Engine {
                       const float* style_dp, const float* duration_override, const int64_t* utt_ids);
     void batch_set_noise(const float* noise, int L);  // injected xt for the L the durations imply
     void batch_run(int total_step, float speed, uint64_t noise_seed);
+    // hipGraph replay of the post-duration pipeline (text encoder, noise, Euler loop, vocoder): captured the second time
+    // a shape is seen, replayed afterwards; per-call data (latent lengths, noise seed) travel through pinned host buffers.
+    void set_graph_mode(bool on) { graph_on_ = on; }
+    long graph_replays() const { return graph_replays_; }
     const Batch& batch() const { return bt_; }
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
     // waveform as 16-bit PCM (clamp, *32767, truncate: cpp/helper.cpp:986-987) converted on the GPU: half the D2H bytes
@@ -188,6 +192,20 @@ class Engine {
     Batch bt_;
     std::vector<void*> batch_owned_;
     std::vector<float> reported_dur_;
+    void enqueue_after_duration(int total_step);
+    struct GraphKey {
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+    };
+    bool graph_on_ = true;
+    GraphKey graph_key_, warm_key_;
+    hipGraphExec_t graph_exec_ = nullptr;
+    hipGraph_t graph_ = nullptr;
+    long graph_replays_ = 0;
+    int* pin_llen_ = nullptr; size_t pin_llen_cap_ = 0;   // pinned host staging read by the graph's memcpy node
+    unsigned long long* pin_seed_ = nullptr;
+    bool pin_valid_ = false;
+    unsigned long long* seed_dev_ = nullptr;
     int final_xt_ = 0;
     bool prof_on_ = false;
     std::vector<ProfSpan> spans_;

@@ -79,7 +79,7 @@ void launch_softplus(hipStream_t s, float* x, int n);
 void launch_scale(hipStream_t s, float* x, int n, float mul);
 // Philox4x32-10 + Box-Muller noise, masked: xt[b][d][t] = t < len[b] ? N(0,1) : 0
 void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, int B, int D, int L, const int* len,
-                         float* xt);
+                         float* xt, const unsigned long long* seed_dev = nullptr /* read the seed from device memory (graph replay) */);
 // xt[b][d][t] *= (t < len[b])
 void launch_mask_ncl(hipStream_t s, float* x, int B, int D, int L, const int* len);
 // out[i] = 1 / in[i]

@@ -607,8 +607,10 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
-__global__ void randn_masked_kernel(unsigned long long seed, const int64_t* __restrict__ utt_ids, int D, int L,
-                                    const int* __restrict__ len, int64_t n4, float* __restrict__ xt) {
+__global__ void randn_masked_kernel(unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                    const int64_t* __restrict__ utt_ids, int D, int L, const int* __restrict__ len, int64_t n4,
+                                    float* __restrict__ xt) {
+    if (seed_dev) seed = *seed_dev;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][D][ceil(L/4)]
     if (i >= n4) return;
     const int L4 = (L + 3) >> 2;
@@ -636,11 +638,11 @@ __global__ void randn_masked_kernel(unsigned long long seed, const int64_t* __re
     }
 }
 void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, int B, int D, int L, const int* len,
-                         float* xt) {
+                         float* xt, const unsigned long long* seed_dev) {
     const int64_t n4 = (int64_t)B * D * ((L + 3) / 4);
     if (n4 == 0) return;
     hipLaunchKernelGGL(randn_masked_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (unsigned long long)seed,
-                       utt_ids, D, L, len, n4, xt);
+                       seed_dev, utt_ids, D, L, len, n4, xt);
 }
 
 __global__ void mask_ncl_kernel(float* __restrict__ x, int D, int L, int64_t n, const int* __restrict__ len) {

@@ -96,3 +96,31 @@ def test_speed_scales_duration_and_length(eng):
     _, L2, _ = eng.batch_dims()
     np.testing.assert_allclose(d2 * 2, d1, rtol=1e-6)  # duration /= speed (cpp/helper.cpp:529-531)
     assert L2 <= (L1 + 1) // 2 + 1
+
+
+def test_graph_replay_equals_eager(eng):
+    """The hipGraph replay of a shape must reproduce the eager result bit for bit, also when the per-call data (lengths, seed)
+    change between replays of the same shape."""
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 10, [10, 7, 4], seed=8)
+    d_a = np.array([0.30, 0.28, 0.11], np.float32)
+    d_b = np.array([0.30, 0.10, 0.25], np.float32)  # same L (max unchanged), different per-utterance lengths
+    eng.set_graph_mode(False)
+    eng.batch_upload(ids, mask, sttl, sdp, d_a)
+    eng.batch_run(2, 1.0, 11)
+    wa, _ = eng.batch_fetch()
+    eng.batch_upload(ids, mask, sttl, sdp, d_b)
+    eng.batch_run(2, 1.0, 12)
+    wb, _ = eng.batch_fetch()
+    eng.set_graph_mode(True)
+    r0 = eng.graph_replays
+    eng.batch_upload(ids, mask, sttl, sdp, d_a)
+    for _ in range(3):  # eager warm-up, capture + replay, replay
+        eng.batch_run(2, 1.0, 11)
+    g1, _ = eng.batch_fetch()
+    assert eng.graph_replays >= r0 + 2 and np.array_equal(g1, wa)
+    eng.batch_upload(ids, mask, sttl, sdp, d_b)  # new upload: new device buffers -> re-captured; then replayed with new data
+    for _ in range(3):
+        eng.batch_run(2, 1.0, 12)
+    g2, _ = eng.batch_fetch()
+    assert np.array_equal(g2, wb)
