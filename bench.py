@@ -42,7 +42,7 @@ def main():
     import torch.distributed as dist
     from supertonic_amd import binding, host, workload
     from supertonic_amd.arch import default_arch
-    from supertonic_amd.dist import gather_waveforms, shard_by_length
+    from supertonic_amd.dist import GatherPlan, shard_by_length
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,12 +86,13 @@ def main():
         eng.batch_run(args.total_step, args.speed, 1234)
         if use_dist:
             B, L, W = eng.batch_dims()
-            if gather_buf.get("shape") != (B, W):
+            if gather_buf.get("shape") != (B, W):  # first step only: buffers + the one-time shape exchange
                 gather_buf["wav"] = torch.empty((B, W), dtype=torch.float32, device=dev)
                 gather_buf["dur"] = torch.tensor(durs / args.speed, dtype=torch.float32, device=dev)
+                gather_buf["plan"] = GatherPlan((B, W), dev, torch.float32, dst=0)
                 gather_buf["shape"] = (B, W)
             eng.batch_copy_wav_device(gather_buf["wav"].data_ptr(), W)
-            gather_waveforms(gather_buf["wav"], gather_buf["dur"], dst=0)
+            gather_buf["plan"].gather(gather_buf["wav"], gather_buf["dur"])
 
     def fence():
         if use_dist:

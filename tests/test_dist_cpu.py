@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from supertonic_amd import workload
-from supertonic_amd.dist import gather_waveforms, shard_by_length
+from supertonic_amd.dist import GatherPlan, gather_waveforms, shard_by_length
 
 
 def test_shard_by_length_balances_and_partitions():
@@ -40,6 +40,12 @@ def _worker(rank, world, port, q):
         wav = torch.arange(B * W, dtype=torch.float32).reshape(B, W) + 1000 * rank
         dur = torch.arange(B, dtype=torch.float32) + 10 * rank
         wavs, durs = gather_waveforms(wav, dur, dst=0)
+        plan = GatherPlan((B, W), wav.device, wav.dtype, dst=0)  # the steady-state form used by bench.py: plan once, gather often
+        for rep in range(2):
+            w2, d2 = plan.gather(wav + rep, dur)
+            if rank == 0 and not all(torch.equal(a, b + rep) for a, b in zip(w2, wavs)):
+                q.put(False)
+                return
         if rank == 0:
             ok = len(wavs) == world
             for r in range(world):
