@@ -155,6 +155,20 @@ def main():
                 roof["timing_note"] = ("avg_launch_us is a HIP-event span on the engine's stream (includes the ~2-5 us dispatch boundary); "
                                        "rocprof_avg_us is the kernel's own duration from the committed kernel trace")
 
+    # ---- the same K steps as hipGraph replays (no event timing possible inside a graph): informational, not `value` --------
+    graph = None
+    if not args.no_profile:
+        eng.profile_enable(False)
+        for _ in range(3):  # eager warm-up of the shape, capture, first replay
+            step()
+        fence()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        tg = time.perf_counter() - tg
+        graph = {"ms_per_step": round(tg / args.steps * 1e3, 3), "replays": eng.graph_replays}
+
     # ---- p50 per-utterance latency: completion time of the batch that contains the utterance ---------------------
     lat = []
     for _ in range(min(5, max(2, args.steps))):
@@ -192,6 +206,11 @@ def main():
             "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM)",
             "roofline": roof,
         }
+        if graph:
+            graph["value"] = round(audio_per_step * (1 if world == 1 else 1) / (graph["ms_per_step"] * 1e-3), 1) if world == 1 else None
+            graph["note"] = ("same workload as hipGraph replays of the post-duration pipeline; `value` above is the eager timed region "
+                             "because HIP events cannot be recorded inside graph replays on ROCm 7.2")
+            out["graph_replay"] = graph
         if fam_stats:
             tot = sum(v["ms"] for v in fam_stats.values())
             top = sorted(fam_stats.items(), key=lambda kv: -kv[1]["ms"])[:8]

@@ -357,6 +357,9 @@ void Engine::prof_end() {
 }
 void Engine::profile_reset() {
     sync();
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }  // its event-record nodes reference pooled events
+    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    graph_key_ = GraphKey();
     for (auto& sp : spans_) { ev_pool_.push_back(sp.a); ev_pool_.push_back(sp.b); }
     spans_.clear();
 }
@@ -366,7 +369,7 @@ std::vector<std::pair<std::string, KernelStat>> Engine::profile_collect() {
     std::vector<std::string> order;
     for (auto& sp : spans_) {
         float ms = 0.f;
-        STN_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) { (void)hipGetLastError(); continue; }  // never recorded
         auto it = acc.find(sp.tag);
         if (it == acc.end()) { order.push_back(sp.tag); it = acc.emplace(sp.tag, KernelStat{}).first; }
         it->second.ms += ms;
@@ -876,6 +879,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
 
     GraphKey key;
     key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
+    // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
     if (graphable && graph_exec_ && key == graph_key_) {
         STN_HIP(hipGraphLaunch(graph_exec_, s_));

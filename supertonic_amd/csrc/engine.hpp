@@ -135,8 +135,8 @@ class Engine {
     void batch_copy_wav_device(float* dst, int64_t dst_stride);
 
     // ---- profiling (hipEvent pairs around launches of one kernel family, on this stream) ----------------
-    void profile_enable(bool on) { prof_on_ = on; }
-    void profile_filter(const std::string& family) { prof_filter_ = family; }  // "" = every family
+    void profile_enable(bool on) { if (on != prof_on_) profile_reset(); prof_on_ = on; }
+    void profile_filter(const std::string& family) { if (family != prof_filter_) profile_reset(); prof_filter_ = family; }  // "" = every family
     void profile_reset();
     std::vector<std::pair<std::string, KernelStat>> profile_collect();
 
