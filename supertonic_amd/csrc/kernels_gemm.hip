@@ -787,7 +787,7 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         } else if (K % 64 == 0) cfg = M <= 64 ? 12 : 8;
         else return false;
     }
-    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg >= 12) && K % 64) return false;
+    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14) && K % 64) return false;
     switch (cfg) {
         case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
         case 2: launch_tiled<MODE, 256, 128, 4, 2, 5, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
@@ -803,6 +803,9 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         case 12: launch_tiled<MODE, 64, 64, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;    // tiny M
         case 13: launch_tiled<MODE, 128, 128, 4, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;  // 16 waves, 4 per SIMD
         case 14: launch_tiled<MODE, 128, 64, 4, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;   // more tiles for narrow N
+        case 15: launch_tiled<MODE, 128, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 48 KiB: 3 WGs / CU
+        case 16: launch_tiled<MODE, 128, 256, 2, 4, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB, 8 waves: 2 WGs / CU
+        case 17: launch_tiled<MODE, 256, 128, 4, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB, 8 waves: 2 WGs / CU
         default: return false;
     }
 }

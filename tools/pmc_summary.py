@@ -22,6 +22,8 @@ def mean_counter(path, name):
 
 
 fetch, nf = mean_counter(a.fetch, "FETCH_SIZE")
+if fetch is None:
+    raise SystemExit("no FETCH_SIZE rows match (check --kernel-substr / --grid)")
 write, nw = mean_counter(a.write, "WRITE_SIZE")
 out = {}
 if os.path.exists(a.out):
