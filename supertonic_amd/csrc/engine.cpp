@@ -318,6 +318,11 @@ void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<s
         std::vector<float> wt(w.size());                                     // stored [ld*k][C]
         for (int co = 0; co < C; ++co) for (int i = 0; i < ld * k; ++i) wt[(size_t)i * C + co] = w[(size_t)co * ld * k + i];
         upload("vo.in.wt", wt, ld * k, C, false);
+        // GEMM form of the same conv: [C][ld*k] with K zero-padded to a multiple of 64 (im2col rows are padded alike)
+        const int kp = (ld * k + 63) / 64 * 64;
+        std::vector<float> wp((size_t)C * kp, 0.f);
+        for (int co = 0; co < C; ++co) std::copy(w.begin() + (size_t)co * ld * k, w.begin() + (size_t)(co + 1) * ld * k, wp.begin() + (size_t)co * kp);
+        upload("vo.in_gemm.w", wp, C, kp, true);
         decl("vo.in.b", K_BIAS, 1, C, 1.f, false, false);
     }
     for (int i = 0; i < a.vo_blocks; ++i) decl_convnext(S("vo.blk%d", i), a.vo_dim, a.vo_hidden, a.vo_kernel);
@@ -641,10 +646,21 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav) {
     const int64_t M = (int64_t)B * T;
     const Arena::Mark mk = ar_.mark();
     float* x = f32_alloc(M * C);
-    if (prof_on_) prof_begin("vocoder_in", 2.0 * M * C * a.latent_dim * a.vo_in_kernel, (double)M * (a.latent_dim + C) * 4.0);
-    launch_vocoder_in(s_, latent, B, L, a.latent_dim, a.chunk_compress_factor, vecf("vo.in.wt"), vecf("vo.in.b"), C,
-                      a.vo_in_kernel, x);
-    if (prof_on_) prof_end();
+    if (dt_ == BF16) {
+        // input conv on the MFMA path: im2col (K = ld*k padded to 64) + GEMM; ~10x the direct fp32 VALU kernel
+        const int kp = (a.latent_dim * a.vo_in_kernel + 63) / 64 * 64;
+        void* cols = act_alloc(M * kp);
+        launch_vocoder_im2col(s_, dt_, latent, B, L, a.latent_dim, a.chunk_compress_factor, a.vo_in_kernel, kp, cols);
+        Linear lin;
+        lin.w = tensor("vo.in_gemm.w"); lin.b = vecf("vo.in.b"); lin.N = C; lin.K = kp;
+        Epilogue ei; ei.mode = EPI_STORE; ei.out_dtype = F32; ei.out = x; ei.ldo = C;
+        gemm("gemm_in", dt_, cols, kp, lin, (int)M, ei);
+    } else {
+        if (prof_on_) prof_begin("vocoder_in", 2.0 * M * C * a.latent_dim * a.vo_in_kernel, (double)M * (a.latent_dim + C) * 4.0);
+        launch_vocoder_in(s_, latent, B, L, a.latent_dim, a.chunk_compress_factor, vecf("vo.in.wt"), vecf("vo.in.b"), C,
+                          a.vo_in_kernel, x);
+        if (prof_on_) prof_end();
+    }
     for (int i = 0; i < a.vo_blocks; ++i)
         convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i], nullptr);
     void* xn = act_alloc(M * C);

@@ -71,6 +71,9 @@ void launch_time_embed(hipStream_t s, const float* cur, const float* tot, int B,
 // vocoder front: un-compress [B,D,L] -> frames [B*T][ld] and conv1d ld->C (kernel k, 'same'), fp32 out
 void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld, int ccf, const float* w /*[C][ld][k]*/,
                        const float* bias, int C, int k, float* x);
+// vocoder front as im2col for the MFMA path: cols[r][ci*k + j] = frame(t + j - k/2)[ci] (0 outside the sequence / beyond ld*k),
+// frame (b, t = l*ccf + q) channel c <- latent[b][q*ld + c][l]; row stride kp (>= ld*k, zero padded), act dtype
+void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols);
 // masked mean over valid rows: pooled[b][c] = sum_{t<len[b]} x[b*L+t][c] / max(len[b],1)   (x act dtype, out fp32)
 void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled);
 // y = softplus(x) elementwise (n small)

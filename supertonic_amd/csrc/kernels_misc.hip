@@ -542,6 +542,35 @@ void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld,
     hipLaunchKernelGGL(vocoder_in_kernel, dim3(B * tiles), dim3(256), lds, s, latent, L, ld, ccf, w_t, bias, C, k, x);
 }
 
+template <typename OutT>
+__global__ void vocoder_im2col_kernel(const float* __restrict__ latent, int L, int ld, int ccf, int k, int kp, int64_t n,
+                                      OutT* __restrict__ cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B*T][kp]
+    if (i >= n) return;
+    const int col = (int)(i % kp);
+    const int64_t r = i / kp;
+    const int T = L * ccf, D = ld * ccf;
+    const int t = (int)(r % T);
+    const int64_t b = r / T;
+    float v = 0.f;
+    if (col < ld * k) {
+        const int ci = col / k, j = col - ci * k;
+        const int tt = t + j - ((k - 1) >> 1);
+        if (tt >= 0 && tt < T) {
+            const int l = tt / ccf, q = tt - l * ccf;
+            v = latent[(b * D + q * ld + ci) * L + l];
+        }
+    }
+    store1(cols + i, v);
+}
+void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols) {
+    const int64_t n = (int64_t)B * L * ccf * kp;
+    if (n == 0) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (out_dtype == BF16) hipLaunchKernelGGL(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols));
+    else hipLaunchKernelGGL(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols));
+}
+
 template <typename InT>
 __global__ void masked_mean_kernel(const InT* __restrict__ x, int L, int C, const int* __restrict__ len,
                                    float* __restrict__ pooled) {
