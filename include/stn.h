@@ -97,6 +97,11 @@ int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_see
 /* hipGraph replay of the post-duration pipeline (default on): a shape is captured the second time it is run and replayed
  * afterwards; stn_graph_replays counts replays (tests / diagnostics) */
 int stn_set_graph_mode(stn_handle* h, int on);
+/* Vocoder treatment of the padding in stn_batch_run.  0 (default) = the reference's batched Run (cpp/helper.cpp:668-679):
+ * all L*ccf frames of every utterance are decoded, the padding being zero latent.  1 = length-aware: each utterance's frames
+ * end at its own latent length, so wav[b, :len_b] is what a batch-of-one synthesis of utterance b gives — the mode in which
+ * the chunks of a long text (TextToSpeech::call, cpp/helper.cpp:685-722, one _infer per chunk) run as ONE batch. */
+int stn_set_vocoder_mode(stn_handle* h, int length_aware);
 int64_t stn_graph_replays(const stn_handle* h);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
 int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);
@@ -131,6 +136,10 @@ int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A /*
 int stn_op_gemm_bench(stn_handle* h, int dtype, int M, int N, int K, int mode, int iters, double* avg_ms);
 int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x,
                      const float* w /*[C,k]*/, const float* bias, const float* ln_g, const float* ln_b, float* y);
+/* same with per-sequence valid lengths (taps at t >= seqlen[b] read as zero, rows t >= seqlen[b] come back as zeros) */
+int stn_op_dwconv_ln_ragged(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x,
+                            const float* w /*[C,k]*/, const float* bias, const float* ln_g, const float* ln_b,
+                            const int32_t* seqlen /*[B], 0..L*/, float* y);
 int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
                      const float* v, const int32_t* qlen_or_null, const int32_t* klen_or_null, int rope_mode, float* o);
 int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids_or_null,

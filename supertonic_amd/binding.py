@@ -28,6 +28,7 @@ class StnConfig(ctypes.Structure):
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 
 
 def load():
@@ -59,6 +60,7 @@ def load():
     L.stn_batch_set_noise.argtypes = [vp, _f32p, ci]
     L.stn_batch_run.argtypes = [vp, ci, cf, cu64]
     L.stn_set_graph_mode.argtypes = [vp, ci]
+    L.stn_set_vocoder_mode.argtypes = [vp, ci]
     L.stn_graph_replays.restype = ctypes.c_int64
     L.stn_graph_replays.argtypes = [vp]
     L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
@@ -79,6 +81,7 @@ def load():
     L.stn_op_gemm.argtypes = [vp, ci, ci, ci, ci, _f32p, _f32p, vp, ci, _f32p]
     L.stn_op_gemm_bench.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     L.stn_op_dwconv_ln.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+    L.stn_op_dwconv_ln_ragged.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p]
     L.stn_op_attention.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, vp, vp, ci, _f32p]
     L.stn_op_randn.argtypes = [vp, cu64, ci, ci, ci, vp, vp, _f32p]
     _LIB = L
@@ -206,6 +209,10 @@ class Engine:
     def set_graph_mode(self, on=True):
         self._ck(self._lib.stn_set_graph_mode(self._h, int(on)))
 
+    def set_vocoder_mode(self, length_aware):
+        """False: the reference's batched vocoder (padding decoded as zero latent). True: every utterance ends at its own length."""
+        self._ck(self._lib.stn_set_vocoder_mode(self._h, int(bool(length_aware))))
+
     @property
     def graph_replays(self):
         return self._lib.stn_graph_replays(self._h)
@@ -298,10 +305,15 @@ class Engine:
                                              iters, ctypes.byref(ms)))
         return ms.value
 
-    def op_dwconv_ln(self, x, w, bias, g, b, dil, dtype=None):
+    def op_dwconv_ln(self, x, w, bias, g, b, dil, dtype=None, seqlen=None):
         B, L, C = x.shape
         k = w.shape[1]
         y = np.empty((B, L, C), np.float32)
+        if seqlen is not None:
+            self._ck(self._lib.stn_op_dwconv_ln_ragged(self._h, self.dtype if dtype is None else _DTYPES[dtype], B, L, C, k,
+                                                       dil, _c(x, np.float32), _c(w, np.float32), _c(bias, np.float32),
+                                                       _c(g, np.float32), _c(b, np.float32), _c(seqlen, np.int32), y))
+            return y
         self._ck(self._lib.stn_op_dwconv_ln(self._h, self.dtype if dtype is None else _DTYPES[dtype], B, L, C, k, dil,
                                             _c(x, np.float32), _c(w, np.float32), _c(bias, np.float32),
                                             _c(g, np.float32), _c(b, np.float32), y))

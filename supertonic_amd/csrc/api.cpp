@@ -244,6 +244,7 @@ int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_see
                  h->eng->batch_run(total_step, speed, noise_seed); })
 }
 int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_mode(on != 0); }) }
+int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }
 int64_t stn_graph_replays(const stn_handle* h) { return h ? h->eng->graph_replays() : 0; }
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len) {
     if (!h) return STN_ERR_INVALID;
@@ -308,6 +309,13 @@ int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int d
     STN_TRY(h, { need(B > 0 && L > 0 && C > 0 && C % 4 == 0 && C <= 1024 && k > 0 && (k & 1) && dil > 0 && x && w && bias && g && b && y,
                       "stn_op_dwconv_ln: bad argument");
                  h->eng->op_dwconv_ln(dtype, B, L, C, k, dil, x, w, bias, g, b, y); })
+}
+int stn_op_dwconv_ln_ragged(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w,
+                            const float* bias, const float* g, const float* b, const int32_t* seqlen, float* y) {
+    STN_TRY(h, { need(B > 0 && L > 0 && C > 0 && C % 4 == 0 && C <= 1024 && k > 0 && (k & 1) && dil > 0 && x && w && bias && g && b && y && seqlen,
+                      "stn_op_dwconv_ln_ragged: bad argument");
+                 for (int i = 0; i < B; ++i) need(seqlen[i] >= 0 && seqlen[i] <= L, "stn_op_dwconv_ln_ragged: seqlen out of [0, L]");
+                 h->eng->op_dwconv_ln(dtype, B, L, C, k, dil, x, w, bias, g, b, y, seqlen); })
 }
 int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
                      const float* v, const int32_t* qlen, const int32_t* klen, int rope_mode, float* o) {

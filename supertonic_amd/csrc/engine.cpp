@@ -118,6 +118,7 @@ Engine::~Engine() {
     if (s_) (void)hipStreamSynchronize(s_);
     free_weights();
     for (void* p : batch_owned_) (void)hipFree(p);
+    for (void* p : batch_retired_) (void)hipFree(p);
     for (auto& sp : spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
@@ -409,13 +410,14 @@ void* Engine::to_act(const float* src, int64_t n) {
 }
 
 // x <- (x + gamma * pw2(GELU(pw1(LN(dwconv(x)))))) * mask      (in place, x fp32 [B*L][C])
-void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len) {
+void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
+                      const int* conv_len) {
     const int64_t M = (int64_t)B * L;
     const Arena::Mark mk = ar_.mark();
     void* xn = act_alloc(M * C);
     void* u = act_alloc(M * hid);
     if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (dt_ == BF16 ? 2.0 : 4.0)));
-    launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn);
+    launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, conv_len);
     if (prof_on_) prof_end();
     Epilogue e1;
     e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
@@ -639,7 +641,11 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     ar_.release(mk);
 }
 
-void Engine::vocoder_dev(int B, int L, const float* latent, float* wav) {
+// vlen == nullptr: every utterance is decoded over all T frames (the reference's batched vocoder Run: the padding is
+// zero latent, which the convolutions see as signal).  vlen != nullptr (length-aware): convolution taps beyond an
+// utterance's own length read as the zero padding of a batch-of-one run, so wav[b, :vlen[b]*hop] equals what
+// synthesizing utterance b alone gives; samples past that are written as zeros.
+void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen) {
     stage_ = "vo";
     const stn_arch& a = a_;
     const int C = a.vo_dim, T = L * a.chunk_compress_factor;
@@ -650,7 +656,7 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav) {
         // input conv on the MFMA path: im2col (K = ld*k padded to 64) + GEMM; ~10x the direct fp32 VALU kernel
         const int kp = (a.latent_dim * a.vo_in_kernel + 63) / 64 * 64;
         void* cols = act_alloc(M * kp);
-        launch_vocoder_im2col(s_, dt_, latent, B, L, a.latent_dim, a.chunk_compress_factor, a.vo_in_kernel, kp, cols);
+        launch_vocoder_im2col(s_, dt_, latent, B, L, a.latent_dim, a.chunk_compress_factor, a.vo_in_kernel, kp, cols, vlen);
         Linear lin;
         lin.w = tensor("vo.in_gemm.w"); lin.b = vecf("vo.in.b"); lin.N = C; lin.K = kp;
         Epilogue ei; ei.mode = EPI_STORE; ei.out_dtype = F32; ei.out = x; ei.ldo = C;
@@ -658,16 +664,16 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav) {
     } else {
         if (prof_on_) prof_begin("vocoder_in", 2.0 * M * C * a.latent_dim * a.vo_in_kernel, (double)M * (a.latent_dim + C) * 4.0);
         launch_vocoder_in(s_, latent, B, L, a.latent_dim, a.chunk_compress_factor, vecf("vo.in.wt"), vecf("vo.in.b"), C,
-                          a.vo_in_kernel, x);
+                          a.vo_in_kernel, x, vlen);
         if (prof_on_) prof_end();
     }
     for (int i = 0; i < a.vo_blocks; ++i)
-        convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i], nullptr);
+        convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i], nullptr, vlen);
     void* xn = act_alloc(M * C);
     const LNorm ln = lnorm("vo.out_ln");
     launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
     // head: transposed conv with kernel = stride = base_chunk_size == per-frame linear; rows of the GEMM output ARE the wave
-    Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wav; e.ldo = a.base_chunk_size;
+    Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wav; e.ldo = a.base_chunk_size; e.len = vlen; e.L = T;
     gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
     ar_.release(mk);
 }
@@ -755,23 +761,25 @@ void Engine::vocoder(int B, int L, const float* latent, float* wav) {
 // resident batch
 // =================================================================================================
 namespace {
-template <typename T>
-void grow(std::vector<void*>& owned, T*& p, size_t& cap, size_t need) {
-    if (need <= cap && p) return;
-    T* n = nullptr;
-    STN_HIP(hipMalloc(reinterpret_cast<void**>(&n), std::max<size_t>(need, 64) * sizeof(T)));
-    owned.push_back(n);  // the old buffer stays owned until the next upload (no free while work may be in flight)
-    p = n;
-    cap = need;
-}
-template <typename T>
-T* dmalloc(std::vector<void*>& owned, size_t n) {
-    T* p = nullptr;
-    STN_HIP(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 64) * sizeof(T)));
-    owned.push_back(p);
-    return p;
-}
 }  // namespace
+
+// Grow-only device buffer of the resident batch.  A reallocation retires the old block (freed at the next upload, once the
+// stream has drained) and bumps the generation that is part of the graph key: a captured graph holds raw pointers.
+template <typename T>
+void Engine::ensure(T*& p, size_t& cap, size_t need) {
+    if (p && need <= cap) return;
+    const size_t n = std::max<size_t>(need + need / 4, 64);  // headroom: ragged request streams settle after a few uploads
+    T* q = nullptr;
+    STN_HIP(hipMalloc(reinterpret_cast<void**>(&q), n * sizeof(T)));
+    if (p) {
+        batch_owned_.erase(std::find(batch_owned_.begin(), batch_owned_.end(), static_cast<void*>(p)));
+        batch_retired_.push_back(p);
+    }
+    batch_owned_.push_back(q);
+    p = q;
+    cap = n;
+    ++bt_.gen;
+}
 
 void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_mask, const float* style_ttl,
                           const float* style_dp, const float* duration_override, const int64_t* utt_ids) {
@@ -779,20 +787,20 @@ void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_m
     if (!loaded_) throw std::runtime_error("no model loaded");
     if (B <= 0 || Lt <= 0) throw std::runtime_error("empty batch");
     sync();
-    for (void* p : batch_owned_) (void)hipFree(p);
-    batch_owned_.clear();
-    bt_ = Batch{};
+    for (void* p : batch_retired_) (void)hipFree(p);
+    batch_retired_.clear();
     Batch& b = bt_;
-    b.B = B; b.Lt = Lt;
+    b.B = B; b.Lt = Lt; b.L = 0; b.noise_L = 0; b.total_step = 0;
+    b.have_override = false; b.have_noise = false;
+    b.h_dur.clear(); b.h_llen.clear();
     const size_t n_ttl = (size_t)B * a_.n_style_ttl * a_.d_style_ttl, n_dp = (size_t)B * a_.n_style_dp * a_.d_style_dp;
-    b.ids = dmalloc<int64_t>(batch_owned_, (size_t)B * Lt);
-    b.tlen = dmalloc<int>(batch_owned_, B);
-    b.style_ttl = dmalloc<float>(batch_owned_, n_ttl);
-    b.style_dp = dmalloc<float>(batch_owned_, n_dp);
-    b.dur = dmalloc<float>(batch_owned_, B);
-    b.llen = dmalloc<int>(batch_owned_, B);
-    b.utt_ids = dmalloc<int64_t>(batch_owned_, B);
-    b.steps = dmalloc<float>(batch_owned_, (size_t)2 * B);
+    ensure(b.ids, b.ids_cap, (size_t)B * Lt);
+    ensure(b.tlen, b.tlen_cap, (size_t)B);
+    ensure(b.style_ttl, b.ttl_cap, n_ttl);
+    ensure(b.style_dp, b.dp_cap, n_dp);
+    ensure(b.dur, b.dur_cap, (size_t)B);
+    ensure(b.llen, b.llen_cap, (size_t)B);
+    ensure(b.utt_ids, b.utt_cap, (size_t)B);
     STN_HIP(hipMemcpyAsync(b.ids, ids, sizeof(int64_t) * B * Lt, hipMemcpyHostToDevice, s_));
     STN_HIP(hipMemcpyAsync(b.style_ttl, style_ttl, sizeof(float) * n_ttl, hipMemcpyHostToDevice, s_));
     STN_HIP(hipMemcpyAsync(b.style_dp, style_dp, sizeof(float) * n_dp, hipMemcpyHostToDevice, s_));
@@ -814,7 +822,7 @@ void Engine::batch_set_noise(const float* noise, int L) {
     if (L < 1) throw std::runtime_error("batch_set_noise: L must be >= 1");
     const int D = a_.latent_dim * a_.chunk_compress_factor;
     sync();
-    grow(batch_owned_, b.noise, b.noise_cap, (size_t)b.B * D * L);
+    ensure(b.noise, b.noise_cap, (size_t)b.B * D * L);
     STN_HIP(hipMemcpyAsync(b.noise, noise, sizeof(float) * b.B * D * L, hipMemcpyHostToDevice, s_));
     b.have_noise = true;
     b.noise_L = L;  // checked against the durations in batch_run
@@ -864,14 +872,9 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     b.L = L;
     reported_dur_ = dur;  // durations after /speed: what the reference returns (cpp/helper.cpp:680)
     const size_t nx = (size_t)B * D * L, nw = (size_t)B * L * a.base_chunk_size * a.chunk_compress_factor;
-    if (nx > b.xt_cap) {
-        size_t c0 = 0, c1 = 0;
-        b.xt[0] = nullptr; b.xt[1] = nullptr;
-        grow(batch_owned_, b.xt[0], c0, nx);
-        grow(batch_owned_, b.xt[1], c1, nx);
-        b.xt_cap = nx;
-    }
-    grow(batch_owned_, b.wav, b.wav_cap, nw);
+    ensure(b.xt[0], b.xt_cap[0], nx);
+    ensure(b.xt[1], b.xt_cap[1], nx);
+    ensure(b.wav, b.wav_cap, nw);
     // per-call data of the captured region lives in pinned host memory (the graph's memcpy nodes re-read it at replay)
     if ((size_t)B > pin_llen_cap_) {
         if (pin_llen_) { sync(); (void)hipHostFree(pin_llen_); }
@@ -894,7 +897,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     }
 
     GraphKey key;
-    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
+    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.gen = b.gen; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
     if (graphable && graph_exec_ && key == graph_key_) {
@@ -965,7 +968,13 @@ void Engine::enqueue_after_duration(int total_step) {
     }
     final_xt_ = cur;
     // 5. vocoder
-    vocoder_dev(B, L, b.xt[cur], b.wav);
+    const int* vlen = nullptr;
+    if (vo_ragged_) {
+        int* v = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+        launch_scale_len(s_, b.llen, B, a.chunk_compress_factor, v);
+        vlen = v;
+    }
+    vocoder_dev(B, L, b.xt[cur], b.wav, vlen);
 }
 
 void Engine::batch_fetch(float* wav, size_t wav_capacity, float* duration) {
@@ -984,7 +993,7 @@ void Engine::batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration) {
     const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
     if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
     if (capacity < nw) throw std::runtime_error("pcm buffer too small: need " + std::to_string(nw) + " samples");
-    grow(batch_owned_, b.pcm, b.pcm_cap, nw);
+    ensure(b.pcm, b.pcm_cap, nw);
     launch_f32_to_pcm16(s_, b.wav, (int64_t)nw, b.pcm);
     STN_HIP(hipMemcpyAsync(pcm, b.pcm, nw * 2, hipMemcpyDeviceToHost, s_));
     sync();
@@ -1030,10 +1039,11 @@ void Engine::op_gemm(int dtype, int M, int N, int K, const float* A, const float
 }
 
 void Engine::op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w, const float* bias,
-                          const float* g, const float* b, float* y) {
+                          const float* g, const float* b, float* y, const int* seqlen) {
     STN_HIP(hipSetDevice(device_));
     ar_.reset();
     const size_t n = (size_t)B * L * C;
+    const int* dlen = seqlen ? up(ar_, s_, seqlen, (size_t)B) : nullptr;
     std::vector<float> wt((size_t)C * k);
     for (int c = 0; c < C; ++c) for (int j = 0; j < k; ++j) wt[(size_t)j * C + c] = w[(size_t)c * k + j];
     float* dx = up(ar_, s_, x, n);
@@ -1043,7 +1053,7 @@ void Engine::op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const 
     float* dbt = up(ar_, s_, b, (size_t)C);
     void* dy = ar_.alloc(n * 4);
     float* dy32 = f32_alloc(n);
-    launch_dwconv_ln(s_, dtype, dx, B, L, C, dw, db, k, dil, dg, dbt, 1e-6f, dy);
+    launch_dwconv_ln(s_, dtype, dx, B, L, C, dw, db, k, dil, dg, dbt, 1e-6f, dy, dlen);
     if (dtype == BF16) launch_bf16_to_f32(s_, static_cast<const uint16_t*>(dy), (int64_t)n, dy32);
     STN_HIP(hipMemcpyAsync(y, dtype == BF16 ? dy32 : static_cast<float*>(dy), n * 4, hipMemcpyDeviceToHost, s_));
     sync();

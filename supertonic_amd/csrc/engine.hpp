@@ -93,7 +93,8 @@ class Engine {
     // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                      const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr);
-    void vocoder_dev(int B, int L, const float* latent, float* wav);
+    // vlen (optional, device [B]): valid vocoder frames per utterance — the length-aware mode (see set_vocoder_mode)
+    void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr);
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
     void duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur);
@@ -109,13 +110,20 @@ class Engine {
         float speed = 1.f;
         bool have_override = false, have_noise = false;
         uint64_t noise_seed = 0;
-        int64_t* ids = nullptr; int* tlen = nullptr; float* style_ttl = nullptr; float* style_dp = nullptr;
-        float* dur = nullptr; int* llen = nullptr; int64_t* utt_ids = nullptr;
+        // device buffers persist across uploads and only ever grow (no hipFree/hipMalloc per request; a captured graph
+        // stays valid while `gen` — bumped by every reallocation — is unchanged)
+        int64_t* ids = nullptr; size_t ids_cap = 0;
+        int* tlen = nullptr; size_t tlen_cap = 0;
+        float* style_ttl = nullptr; size_t ttl_cap = 0;
+        float* style_dp = nullptr; size_t dp_cap = 0;
+        float* dur = nullptr; size_t dur_cap = 0;
+        int* llen = nullptr; size_t llen_cap = 0;
+        int64_t* utt_ids = nullptr; size_t utt_cap = 0;
         float* noise = nullptr; size_t noise_cap = 0;   // injected noise [B,D,L] (optional)
-        float* xt[2] = {nullptr, nullptr}; size_t xt_cap = 0;
+        float* xt[2] = {nullptr, nullptr}; size_t xt_cap[2] = {0, 0};
         float* wav = nullptr; size_t wav_cap = 0;        // [B, L*cs]
         int16_t* pcm = nullptr; size_t pcm_cap = 0;      // [B, L*cs] int16 (on demand)
-        float* steps = nullptr;                          // [2][B]: total_step, current_step
+        uint64_t gen = 0;
         std::vector<float> h_dur; std::vector<int> h_llen;
     };
     void batch_upload(int B, int Lt, const int64_t* ids, const float* text_mask, const float* style_ttl,
@@ -125,6 +133,8 @@ class Engine {
     // hipGraph replay of the post-duration pipeline (text encoder, noise, Euler loop, vocoder): captured the second time
     // a shape is seen, replayed afterwards; per-call data (latent lengths, noise seed) travel through pinned host buffers.
     void set_graph_mode(bool on) { graph_on_ = on; }
+    // length-aware vocoder in batch_run: every utterance's frames end at its own length, as in a batch-of-one run
+    void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
     long graph_replays() const { return graph_replays_; }
     const Batch& batch() const { return bt_; }
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
@@ -145,7 +155,7 @@ class Engine {
     void op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k, const float* v,
                       const int* qlen, const int* klen, int rope_mode, float* o);
     void op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w, const float* bias,
-                      const float* g, const float* b, float* y);
+                      const float* g, const float* b, float* y, const int* seqlen = nullptr /* host [B] */);
     // device-resident timing of one GEMM shape (random operands), HIP events around `iters` launches: avg ms
     double op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters);
     void op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out);
@@ -169,7 +179,8 @@ class Engine {
     void* act_alloc(int64_t n) { return ar_.alloc(act_bytes(n)); }
     float* f32_alloc(int64_t n) { return static_cast<float*>(ar_.alloc((size_t)n * 4)); }
     void gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e);
-    void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len);
+    void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
+                  const int* conv_len = nullptr);
     void attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
                     const int* klen, int rope_mode, bool self);
     void* to_act(const float* src, int64_t n);
@@ -190,14 +201,17 @@ class Engine {
     std::vector<void*> owned_;
     Arena ar_;
     Batch bt_;
-    std::vector<void*> batch_owned_;
+    std::vector<void*> batch_owned_;    // every live batch buffer (freed with the engine)
+    std::vector<void*> batch_retired_;  // outgrown buffers: freed at the next upload, after the stream has drained
+    template <typename T> void ensure(T*& p, size_t& cap, size_t need);
     std::vector<float> reported_dur_;
     void enqueue_after_duration(int total_step);
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
-        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
     };
     bool graph_on_ = true;
+    bool vo_ragged_ = false;
     GraphKey graph_key_, warm_key_;
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t graph_ = nullptr;

@@ -101,20 +101,44 @@ TextToSpeech::SynthesisResult TextToSpeech::call(const std::string& text, const 
                                                  int total_step, float speed, float silence_duration) {
     if (style.getTtlShape()[0] != 1) throw std::runtime_error("Single speaker text to speech only supports single style");
     const std::vector<std::string> chunks = chunk_text(text, lang == "ko" ? 120 : 300);
+    if (chunks.size() == 1) return infer({chunks[0]}, {lang}, style, total_step, speed);
+    // The reference synthesizes the chunks one after another (cpp/helper.cpp:697-719: one _infer, i.e. four Run calls per
+    // step, per chunk).  Here they form ONE batch with the speaker's style replicated; the length-aware vocoder mode makes
+    // every chunk's wave over its own frames what the batch-of-one run gives, so the joined result keeps the reference's
+    // semantics (untrimmed chunk waves of L_i * chunk_size samples, zeros in between) at one pipeline pass.
+    const int n = (int)chunks.size();
+    const std::vector<int64_t>& ts = style.getTtlShape();
+    const std::vector<int64_t>& ds = style.getDpShape();
+    std::vector<float> ttl, dp;
+    ttl.reserve(style.getTtlData().size() * n);
+    dp.reserve(style.getDpData().size() * n);
+    for (int i = 0; i < n; ++i) {
+        ttl.insert(ttl.end(), style.getTtlData().begin(), style.getTtlData().end());
+        dp.insert(dp.end(), style.getDpData().begin(), style.getDpData().end());
+    }
+    const Style rep(std::move(ttl), {n, ts[1], ts[2]}, std::move(dp), {n, ds[1], ds[2]});
+    struct ModeGuard {
+        stn_handle* h;
+        explicit ModeGuard(stn_handle* hh) : h(hh) { check(h, stn_set_vocoder_mode(h, 1)); }
+        ~ModeGuard() { (void)stn_set_vocoder_mode(h, 0); }
+    } guard(h_);
+    const SynthesisResult r = infer(chunks, std::vector<std::string>((size_t)n, lang), rep, total_step, speed);
+    const size_t W = r.wav.size() / (size_t)n;
+    const int chunk_size = cfgs_.ae.base_chunk_size * cfgs_.ttl.chunk_compress_factor;
+    const size_t n_sil = (size_t)(int)(silence_duration * (float)cfgs_.ae.sample_rate);
     SynthesisResult out;
     float dur_cat = 0.f;
-    bool first = true;
-    for (const std::string& chunk : chunks) {
-        SynthesisResult r = infer({chunk}, {lang}, style, total_step, speed);
-        if (first) {
-            out.wav = std::move(r.wav);
+    for (int i = 0; i < n; ++i) {
+        const LatentGeometry g = latent_geometry({r.duration[(size_t)i]}, cfgs_.ae.sample_rate, cfgs_.ae.base_chunk_size,
+                                                 cfgs_.ttl.chunk_compress_factor, cfgs_.ttl.latent_dim);
+        const size_t n_i = (size_t)g.L * (size_t)chunk_size;  // the wav length the chunk's own run would return
+        if (i > 0) {  // untrimmed chunk waves joined by zeros (cpp/helper.cpp:706-715)
+            out.wav.insert(out.wav.end(), n_sil, 0.0f);
+            dur_cat += r.duration[(size_t)i] + silence_duration;
+        } else {
             dur_cat = r.duration[0];
-            first = false;
-        } else {  // untrimmed chunk waves joined by zeros (cpp/helper.cpp:706-715)
-            out.wav.insert(out.wav.end(), (size_t)(int)(silence_duration * (float)cfgs_.ae.sample_rate), 0.0f);
-            out.wav.insert(out.wav.end(), r.wav.begin(), r.wav.end());
-            dur_cat += r.duration[0] + silence_duration;
         }
+        out.wav.insert(out.wav.end(), r.wav.begin() + (size_t)i * W, r.wav.begin() + (size_t)i * W + std::min(n_i, W));
     }
     out.duration = {dur_cat};
     return out;

@@ -40,8 +40,11 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
 
 // depthwise 'same' conv (taps k, dilation dil, weights TRANSPOSED [k][C]) fused with LayerNorm over C.
 // x fp32 [B*L][C] -> y act [B*L][C].  C % 4 == 0, C <= 1024.
+// seqlen (optional, [B]): frames at t >= seqlen[b] are treated as outside the sequence (zero taps, rows not written) — the
+// length-aware mode in which a padded batch reproduces what each sequence would give on its own
 void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L, int C, const float* w_t,
-                      const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y);
+                      const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y,
+                      const int* seqlen = nullptr);
 // plain LayerNorm over C: x fp32 -> y act
 void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
                       float eps, void* y);
@@ -69,11 +72,13 @@ void launch_add_rowvec(hipStream_t s, float* x, const float* v, int ldv, int B, 
 // time embedding: te[b][:] = [sin(t*f_i), cos(t*f_i)], t = cur[b]/tot[b]*scale
 void launch_time_embed(hipStream_t s, const float* cur, const float* tot, int B, int dim, float scale, float* te);
 // vocoder front: un-compress [B,D,L] -> frames [B*T][ld] and conv1d ld->C (kernel k, 'same'), fp32 out
+void launch_scale_len(hipStream_t s, const int* len, int B, int factor, int* out);  // out[b] = len[b] * factor
 void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld, int ccf, const float* w /*[C][ld][k]*/,
-                       const float* bias, int C, int k, float* x);
+                       const float* bias, int C, int k, float* x, const int* seqlen = nullptr);
 // vocoder front as im2col for the MFMA path: cols[r][ci*k + j] = frame(t + j - k/2)[ci] (0 outside the sequence / beyond ld*k),
 // frame (b, t = l*ccf + q) channel c <- latent[b][q*ld + c][l]; row stride kp (>= ld*k, zero padded), act dtype
-void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols);
+void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols,
+                           const int* seqlen = nullptr /* valid vocoder frames per sequence */);
 // masked mean over valid rows: pooled[b][c] = sum_{t<len[b]} x[b*L+t][c] / max(len[b],1)   (x act dtype, out fp32)
 void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled);
 // y = softplus(x) elementwise (n small)

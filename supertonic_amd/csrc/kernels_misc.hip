@@ -50,10 +50,13 @@ template <typename OutT, bool CONV>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, int64_t M, int L, int C,
                                                         const float* __restrict__ w_t, const float* __restrict__ bias,
                                                         int k, int dil, const float* __restrict__ g,
-                                                        const float* __restrict__ bt, float eps, OutT* __restrict__ y) {
+                                                        const float* __restrict__ bt, float eps, OutT* __restrict__ y,
+                                                        const int* __restrict__ seqlen) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;  // wave-uniform
+    const int Lv = (CONV && seqlen) ? seqlen[row / L] : L;       // valid frames of this row's sequence
+    const float live = (CONV && (int)(row % L) >= Lv) ? 0.f : 1.f;  // rows in the padding are written as zeros
     const int C4 = C >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     float4 h[LN_NI];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
                 float4 a = b4[c4];
                 for (int j = 0; j < k; ++j) {
                     const int tt = t + (j - half) * dil;
-                    if (tt >= 0 && tt < L) {
+                    if (tt >= 0 && tt < Lv) {
                         const float4 xv = x4[(base + tt) * C4 + c4];
                         const float4 wv = w4[(int64_t)j * C4 + c4];
                         a.x = fmaf(wv.x, xv.x, a.x); a.y = fmaf(wv.y, xv.y, a.y);
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
         const int c4 = lane + 64 * i;
         if (c4 < C4) {
             const float4 gg = g4[c4], bb = bt4[c4];
-            store4(y + row * C + c4 * 4, (h[i].x - mean) * rstd * gg.x + bb.x, (h[i].y - mean) * rstd * gg.y + bb.y,
-                   (h[i].z - mean) * rstd * gg.z + bb.z, (h[i].w - mean) * rstd * gg.w + bb.w);
+            store4(y + row * C + c4 * 4, live * ((h[i].x - mean) * rstd * gg.x + bb.x), live * ((h[i].y - mean) * rstd * gg.y + bb.y),
+                   live * ((h[i].z - mean) * rstd * gg.z + bb.z), live * ((h[i].w - mean) * rstd * gg.w + bb.w));
         }
     }
 }
@@ -125,7 +128,8 @@ template <typename OutT, int K, int R>
 __global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restrict__ x, int64_t M, int L, int C,
                                                            const float* __restrict__ w_t, const float* __restrict__ bias,
                                                            int dil, const float* __restrict__ g,
-                                                           const float* __restrict__ bt, float eps, OutT* __restrict__ y) {
+                                                           const float* __restrict__ bt, float eps, OutT* __restrict__ y,
+                                                           const int* __restrict__ seqlen) {
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (r0 >= M) return;  // wave-uniform
@@ -134,15 +138,16 @@ __global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restri
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const float4* w4 = reinterpret_cast<const float4*>(w_t);
     const float4* b4 = reinterpret_cast<const float4*>(bias);
-    int tpos[R];
+    int tpos[R], lv[R];
     int64_t base[R];
     bool rowok[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = r0 + r < M ? r0 + r : M - 1;
-        rowok[r] = r0 + r < M;
         tpos[r] = (int)(row % L);
         base[r] = row - tpos[r];
+        lv[r] = seqlen ? seqlen[row / L] : L;
+        rowok[r] = r0 + r < M;
     }
     float4 h[R][2];
 #pragma unroll
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restri
             for (int j = 0; j < K; ++j) {
                 const int tt = tpos[r] + (j - HALF) * dil;
                 const int tc = tt < 0 ? 0 : (tt >= L ? L - 1 : tt);
-                xv[r][j] = x4[(base[r] + tc) * C4 + cc];
+                xv[r][j] = x4[(base[r] + tc) * C4 + cc];  // clamped in-range load; zeroed below when outside [0, lv)
             }
         const float4 bv = b4[cc];
 #pragma unroll
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int tt = tpos[r] + (j - HALF) * dil;
-                const float keep = (tt >= 0 && tt < L) ? 1.f : 0.f;
+                const float keep = (tt >= 0 && tt < lv[r]) ? 1.f : 0.f;
                 a.x = fmaf(wv[j].x * keep, xv[r][j].x, a.x); a.y = fmaf(wv[j].y * keep, xv[r][j].y, a.y);
                 a.z = fmaf(wv[j].z * keep, xv[r][j].z, a.z); a.w = fmaf(wv[j].w * keep, xv[r][j].w, a.w);
             }
@@ -191,13 +196,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restri
             }
         const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
         if (!rowok[r]) continue;  // wave-uniform
+        const float live = tpos[r] < lv[r] ? 1.f : 0.f;  // rows in the padding are written as zeros
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c4 = lane + 64 * i;
             if (c4 < C4) {
                 const float4 gg = g4[c4], bb = bt4[c4];
-                store4(y + (r0 + r) * C + c4 * 4, (h[r][i].x - mean) * rstd * gg.x + bb.x, (h[r][i].y - mean) * rstd * gg.y + bb.y,
-                       (h[r][i].z - mean) * rstd * gg.z + bb.z, (h[r][i].w - mean) * rstd * gg.w + bb.w);
+                store4(y + (r0 + r) * C + c4 * 4, live * ((h[r][i].x - mean) * rstd * gg.x + bb.x), live * ((h[r][i].y - mean) * rstd * gg.y + bb.y),
+                       live * ((h[r][i].z - mean) * rstd * gg.z + bb.z), live * ((h[r][i].w - mean) * rstd * gg.w + bb.w));
             }
         }
     }
@@ -213,15 +219,27 @@ template <typename OutT, int K, int R>
 __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restrict__ x, int nseq, int L, int C,
                                                            const float* __restrict__ w_t, const float* __restrict__ bias,
                                                            int dil, int wps /*waves per sequence*/, const float* __restrict__ g,
-                                                           const float* __restrict__ bt, float eps, OutT* __restrict__ y) {
+                                                           const float* __restrict__ bt, float eps, OutT* __restrict__ y,
+                                                           const int* __restrict__ seqlen) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= (int64_t)nseq * wps) return;  // wave-uniform
     const int b = (int)(wid / wps), rem = (int)(wid % wps);
     const int t0 = (rem / dil) * (R * dil) + (rem % dil);
-    if (t0 >= L) return;
+    const int Lv = seqlen ? seqlen[b] : L;  // valid frames of this sequence (<= L)
     constexpr int HALF = (K - 1) / 2, NWIN = R + K - 1;
     const int C4 = C >> 2;
+    if (t0 >= Lv) {  // the whole comb lies in the padding: its rows are defined (zeros) but cost no loads or arithmetic
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = t0 + r * dil;
+            if (t >= L) break;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (lane + 64 * i < C4) store4(y + ((int64_t)b * L + t) * C + (lane + 64 * i) * 4, 0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const float4* x4 = reinterpret_cast<const float4*>(x) + (int64_t)b * L * C4;
     const float4* w4 = reinterpret_cast<const float4*>(w_t);
     const float4* b4 = reinterpret_cast<const float4*>(bias);
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
             const int tt = t0 + (q - HALF) * dil;
             const int tc = tt < 0 ? 0 : (tt >= L ? L - 1 : tt);
             const float4 v = x4[(int64_t)tc * C4 + cc];
-            const float keep = (tt >= 0 && tt < L) ? 1.f : 0.f;
+            const float keep = (tt >= 0 && tt < Lv) ? 1.f : 0.f;
             win[q] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
         }
         const float4 bv = b4[cc];
@@ -277,6 +295,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
             }
         const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
         if (t >= L) continue;  // wave-uniform (tail of the sequence)
+        if (t >= Lv) {         // padding of a shorter sequence: zeros
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (lane + 64 * i < C4) store4(y + ((int64_t)b * L + t) * C + (lane + 64 * i) * 4, 0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c4 = lane + 64 * i;
@@ -290,25 +314,25 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
 
 template <typename OutT, int K, int R>
 static void launch_dwconv_ln_v3_kr(hipStream_t s, const float* x, int nseq, int L, int C, const float* w_t, const float* bias,
-                                   int dil, const float* g, const float* b, float eps, OutT* y) {
+                                   int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen) {
     const int wps = ((L + R * dil - 1) / (R * dil)) * dil;
     const int64_t nw = (int64_t)nseq * wps;
     hipLaunchKernelGGL((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
-                       dil, wps, g, b, eps, y);
+                       dil, wps, g, b, eps, y, seqlen);
 }
 
 template <typename OutT>
 static bool launch_dwconv_ln_v3(hipStream_t s, const float* x, int nseq, int L, int C, const float* w_t, const float* bias,
-                                int k, int dil, const float* g, const float* b, float eps, OutT* y) {
+                                int k, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen) {
     if (C > 512 || (k != 5 && k != 7)) return false;
     // enough wavefronts to fill the chip (256 CUs x ~8): long combs only when there are many frames
     const int64_t M = (int64_t)nseq * L;
     if (M >= 32768) {
-        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y);
-        else launch_dwconv_ln_v3_kr<OutT, 7, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y);
+        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+        else launch_dwconv_ln_v3_kr<OutT, 7, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
     } else if (M >= 4096) {
-        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y);
-        else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y);
+        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+        else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
     } else {
         return false;  // few frames: one wave per 2 frames (v2) exposes more parallelism
     }
@@ -317,12 +341,12 @@ static bool launch_dwconv_ln_v3(hipStream_t s, const float* x, int nseq, int L, 
 
 template <typename OutT>
 static bool launch_dwconv_ln_v2(hipStream_t s, const float* x, int64_t M, int L, int C, const float* w_t, const float* bias,
-                                int k, int dil, const float* g, const float* b, float eps, OutT* y) {
+                                int k, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen) {
     constexpr int R = 2;
     if (C > 512 || (k != 5 && k != 7)) return false;
     const dim3 grid((unsigned)((M + 4 * R - 1) / (4 * R)));
-    if (k == 5) hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 5, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y);
-    else hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 7, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y);
+    if (k == 5) hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 5, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+    else hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 7, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
     return true;
 }
 
@@ -331,23 +355,24 @@ static void check_ln_shape(int C) {
 }
 
 void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L, int C, const float* w_t,
-                      const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y) {
+                      const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y,
+                      const int* seqlen) {
     check_ln_shape(C);
     const int64_t M = (int64_t)B * L;
     if (M == 0) return;
-    if (out_dtype == BF16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y))
-                          : launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y)))
+    if (out_dtype == BF16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen)
+                          : launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen))
         return;
-    if (out_dtype == BF16 ? launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y))
-                          : launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y)))
+    if (out_dtype == BF16 ? launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen)
+                          : launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen))
         return;
     const dim3 grid((unsigned)((M + 3) / 4));
     if (out_dtype == BF16)
         hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
-                           ln_b, eps, static_cast<uint16_t*>(y));
+                           ln_b, eps, static_cast<uint16_t*>(y), seqlen);
     else
         hipLaunchKernelGGL((dwconv_ln_kernel<float, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b,
-                           eps, static_cast<float*>(y));
+                           eps, static_cast<float*>(y), seqlen);
 }
 
 void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
@@ -357,10 +382,10 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
     const dim3 grid((unsigned)((M + 3) / 4));
     if (out_dtype == BF16)
         hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g,
-                           b, eps, static_cast<uint16_t*>(y));
+                           b, eps, static_cast<uint16_t*>(y), static_cast<const int*>(nullptr));
     else
         hipLaunchKernelGGL((dwconv_ln_kernel<float, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g, b,
-                           eps, static_cast<float*>(y));
+                           eps, static_cast<float*>(y), static_cast<const int*>(nullptr));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,7 +525,7 @@ void launch_time_embed(hipStream_t s, const float* cur, const float* tot, int B,
 static constexpr int VI_FR = 8;
 __global__ __launch_bounds__(256) void vocoder_in_kernel(const float* __restrict__ latent, int L, int ld, int ccf,
                                                          const float* __restrict__ w_t, const float* __restrict__ bias,
-                                                         int C, int k, float* __restrict__ x) {
+                                                         int C, int k, float* __restrict__ x, const int* __restrict__ seqlen) {
     extern __shared__ __attribute__((aligned(16))) float win[];  // [(VI_FR + k - 1)][ld]
     const int T = L * ccf, D = ld * ccf;
     const int tiles = (T + VI_FR - 1) / VI_FR;
@@ -510,7 +535,7 @@ __global__ __launch_bounds__(256) void vocoder_in_kernel(const float* __restrict
         const int f = i / ld, c = i - f * ld;
         const int t = t0 - half + f;
         float v = 0.f;
-        if (t >= 0 && t < T) {
+        if (t >= 0 && t < (seqlen ? seqlen[b] : T)) {
             const int l = t / ccf, j = t - l * ccf;
             v = latent[((int64_t)b * D + j * ld + c) * L + l];
         }
@@ -534,17 +559,17 @@ __global__ __launch_bounds__(256) void vocoder_in_kernel(const float* __restrict
     }
 }
 void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld, int ccf, const float* w_t,
-                       const float* bias, int C, int k, float* x) {
+                       const float* bias, int C, int k, float* x, const int* seqlen) {
     const int T = L * ccf;
     if (B * T == 0) return;
     const int tiles = (T + VI_FR - 1) / VI_FR;
     const size_t lds = sizeof(float) * (size_t)(VI_FR + k - 1) * ld;
-    hipLaunchKernelGGL(vocoder_in_kernel, dim3(B * tiles), dim3(256), lds, s, latent, L, ld, ccf, w_t, bias, C, k, x);
+    hipLaunchKernelGGL(vocoder_in_kernel, dim3(B * tiles), dim3(256), lds, s, latent, L, ld, ccf, w_t, bias, C, k, x, seqlen);
 }
 
 template <typename OutT>
 __global__ void vocoder_im2col_kernel(const float* __restrict__ latent, int L, int ld, int ccf, int k, int kp, int64_t n,
-                                      OutT* __restrict__ cols) {
+                                      OutT* __restrict__ cols, const int* __restrict__ seqlen) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B*T][kp]
     if (i >= n) return;
     const int col = (int)(i % kp);
@@ -556,19 +581,20 @@ __global__ void vocoder_im2col_kernel(const float* __restrict__ latent, int L, i
     if (col < ld * k) {
         const int ci = col / k, j = col - ci * k;
         const int tt = t + j - ((k - 1) >> 1);
-        if (tt >= 0 && tt < T) {
+        if (tt >= 0 && tt < (seqlen ? seqlen[b] : T)) {
             const int l = tt / ccf, q = tt - l * ccf;
             v = latent[(b * D + q * ld + ci) * L + l];
         }
     }
     store1(cols + i, v);
 }
-void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols) {
+void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols,
+                           const int* seqlen) {
     const int64_t n = (int64_t)B * L * ccf * kp;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) hipLaunchKernelGGL(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols));
-    else hipLaunchKernelGGL(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols));
+    if (out_dtype == BF16) hipLaunchKernelGGL(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen);
+    else hipLaunchKernelGGL(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols), seqlen);
 }
 
 template <typename InT>
@@ -672,6 +698,15 @@ void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, i
     if (n4 == 0) return;
     hipLaunchKernelGGL(randn_masked_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (unsigned long long)seed,
                        seed_dev, utt_ids, D, L, len, n4, xt);
+}
+
+__global__ void scale_len_kernel(const int* __restrict__ len, int B, int factor, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) out[i] = len[i] * factor;
+}
+void launch_scale_len(hipStream_t s, const int* len, int B, int factor, int* out) {
+    if (B == 0) return;
+    hipLaunchKernelGGL(scale_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, factor, out);
 }
 
 __global__ void mask_ncl_kernel(float* __restrict__ x, int D, int L, int64_t n, const int* __restrict__ len) {
