@@ -228,6 +228,24 @@ def main():
                     a_ = v["bytes"] / max(v["launches"], 1) / (ms * 1e-3) / 1e9
                     other[k] = {"bound": "hbm", "achieved": round(a_, 1), "unit": "GB/s", "frac": round(a_ / 8000.0, 4), "avg_us": round(ms * 1e3, 1)}
             out["roofline_other"] = other
+            # HBM-roofline fraction of the vocoder STAGE under the fused-ideal byte model (each block reads
+            # its input once and writes its output once), with the stage's MFMA utilisation beside it.  Low by design
+            # for a compute-dense stage: the fused-ideal vocoder sits ~6x above the ridge point.
+            vo_ms = sum(v["ms"] for k, v in fam_stats.items() if k.startswith("vo."))
+            if vo_ms > 0:
+                es = 2 if args.dtype == "bf16" else 4
+                frames = B * L * arch.chunk_compress_factor
+                bytes_frame = es * arch.latent_dim + arch.vo_blocks * 2 * arch.vo_dim * es + arch.base_chunk_size * 4
+                flops_frame = (arch.vo_blocks * (2 * arch.vo_dim * arch.vo_hidden * 2 + 2 * arch.vo_kernel * arch.vo_dim)
+                               + 2 * arch.vo_in_kernel * arch.latent_dim * arch.vo_dim + 2 * arch.vo_dim * arch.base_chunk_size)
+                peak = 2500.0 if args.dtype == "bf16" else 157.3
+                gbs = bytes_frame * frames / (vo_ms * 1e-3) / 1e9
+                tfs = flops_frame * frames / (vo_ms * 1e-3) / 1e12
+                out["vocoder_stage"] = {"frames": frames, "ms": round(vo_ms, 3), "bytes_per_frame_fused_ideal": bytes_frame,
+                                        "flops_per_frame": flops_frame,
+                                        "hbm": {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)},
+                                        "mfma": {"achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tfs / peak, 4)},
+                                        "note": "event-timed spans of every vo.* launch in one fully profiled step"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args)
         print(json.dumps(out))

@@ -140,6 +140,8 @@ int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int d
 int stn_op_dwconv_ln_ragged(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x,
                             const float* w /*[C,k]*/, const float* bias, const float* ln_g, const float* ln_b,
                             const int32_t* seqlen /*[B], 0..L*/, float* y);
+/* rope_mode: -1 none, 0 RoPE on the position index, 1 length-aware RoPE; OR-ing 0x100 makes the engine rotate the keys in
+ * a separate pass first (the way the vector estimator's step-invariant text keys are handled) — same result */
 int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
                      const float* v, const int32_t* qlen_or_null, const int32_t* klen_or_null, int rope_mode, float* o);
 int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids_or_null,

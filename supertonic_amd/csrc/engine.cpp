@@ -411,7 +411,7 @@ void* Engine::to_act(const float* src, int64_t n) {
 
 // x <- (x + gamma * pw2(GELU(pw1(LN(dwconv(x)))))) * mask      (in place, x fp32 [B*L][C])
 void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
-                      const int* conv_len) {
+                      const int* conv_len, const float* rowvec, int rv_ld) {
     const int64_t M = (int64_t)B * L;
     const Arena::Mark mk = ar_.mark();
     void* xn = act_alloc(M * C);
@@ -423,7 +423,7 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
     gemm("gemm_pw1_gelu", dt_, xn, C, p.pw1, (int)M, e1);
     Epilogue e2;
-    e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.gamma = p.gamma; e2.len = len; e2.L = L;
+    e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.gamma = p.gamma; e2.len = len; e2.L = L; e2.rowvec = rowvec; e2.rv_ld = rv_ld;
     gemm("gemm_pw2_resid", dt_, u, hid, p.pw2, (int)M, e2);
     ar_.release(mk);
 }
@@ -541,7 +541,7 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
 
 // K/V of the text and style contexts for every main block: invariant across Euler steps.
 // The returned buffers live in the arena ABOVE the caller's mark: the caller releases them.
-Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl) {
+Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, nb = a.ve_main_blocks;
@@ -551,6 +551,9 @@ Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const
     c.style_kv = act_alloc((int64_t)B * a.n_style_ttl * nb * 2 * C);
     Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = c.text_kv; e.ldo = nb * 2 * C;
     gemm("gemm_kv", dt_, text_rows, a.te_out_dim, linear("ve.text_kv_all"), B * Lt, e);
+    // LARoPE of the text keys does not depend on the Euler step or on the query: rotate all blocks' keys once
+    // (was re-done by every one of the main_blocks x total_step attention launches)
+    launch_rope_rows(s_, dt_, c.text_kv, nb * 2 * C, B, Lt, tlen, nb, 2 * C, a.ve_heads, C / a.ve_heads, 1, a.rope_base, a.larope_gamma);
     void* st = to_act(style_ttl, (int64_t)B * a.n_style_ttl * a.d_style_ttl);
     Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = dt_; e2.out = c.style_kv; e2.ldo = nb * 2 * C;
     gemm("gemm_kv", dt_, st, a.d_style_ttl, linear("ve.style_kv_all"), B * a.n_style_ttl, e2);
@@ -608,7 +611,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         void* o = act_alloc(M * C);
         if (prof_on_) prof_begin("attention", 4.0 * M * (double)Lk * C, (double)(M * 2 + (int64_t)B * Lk * 2) * C * esz);
         launch_attention(s_, dt_, qb, C, kp, vp, nb * 2 * C, o, C, B, L, Lk, H, C / H, llen, klen, rope_mode, a.rope_base,
-                         a.larope_gamma);
+                         a.larope_gamma, /*k_rotated=*/rope_mode >= 0);
         if (prof_on_) prof_end();
         Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = llen; eo.L = L;
         gemm("gemm_attn_out", dt_, o, C, w.o, (int)M, eo);
@@ -617,9 +620,13 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
 
     for (int blk = 0; blk < nb; ++blk) {
         const std::string p = "ve.m" + std::to_string(blk);
-        for (int j = 0; j < a.ve_dilated; ++j)
-            convnext(convnext_w(p + ".dil" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1 << j, llen);
-        launch_add_rowvec(s_, x, tb + (size_t)blk * C, nb * C, B, L, C, llen);
+        // the time conditioning x += tb[b] rides in the residual epilogue of the last dilated block (was a separate pass)
+        for (int j = 0; j < a.ve_dilated; ++j) {
+            const bool last = j == a.ve_dilated - 1;
+            convnext(convnext_w(p + ".dil" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1 << j, llen, nullptr,
+                     last ? tb + (size_t)blk * C : nullptr, nb * C);
+        }
+        if (a.ve_dilated == 0) launch_add_rowvec(s_, x, tb + (size_t)blk * C, nb * C, B, L, C, llen);
         convnext(convnext_w(p + ".cn_a"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
         cross(p + ".text", c.text_kv, blk, c.Lt, tlen, 1);
         convnext(convnext_w(p + ".cn_b"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
@@ -739,7 +746,7 @@ void Engine::vector_est(int B, int L, int Lt, const float* noisy, const float* t
     launch_mask_to_len(s_, d_lm, B, L, llen);
     void* rows = act_alloc((int64_t)B * Lt * Ce);
     launch_ncl_to_rows(s_, dt_, d_emb, B, Ce, Lt, rows);
-    VeCtx c = ve_prepare_dev(B, Lt, rows, d_st);
+    VeCtx c = ve_prepare_dev(B, Lt, rows, d_st, tlen);
     ve_step_dev(B, L, c, d_x, tlen, llen, d_tot, d_cur, d_out);
     STN_HIP(hipMemcpyAsync(denoised, d_out, (size_t)B * D * L * 4, hipMemcpyDeviceToHost, s_));
     sync();
@@ -953,7 +960,7 @@ void Engine::enqueue_after_duration(int total_step) {
         launch_randn_masked(s_, 0, b.utt_ids, B, D, L, b.llen, b.xt[0], seed_dev_);
     }
     // 4. Euler loop: step-invariant K/V once, the time conditioning of every step in one pass, then total_step passes
-    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl);
+    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen);
     float* tot_all = f32_alloc((int64_t)total_step * B);
     float* cur_all = f32_alloc((int64_t)total_step * B);
     launch_fill(s_, tot_all, total_step * B, (float)total_step);
@@ -1078,8 +1085,11 @@ void Engine::op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const
     }
     void* dO = ar_.alloc(nq * 4);
     float* dO32 = f32_alloc(nq);
-    launch_attention(s_, dtype, pq, C, pk, pv, C, dO, C, B, Lq, Lk, H, dh, dql, dkl, rope_mode, a_.rope_base > 0 ? a_.rope_base : 10000.f,
-                     a_.larope_gamma > 0 ? a_.larope_gamma : 10.f);
+    const float rbase = a_.rope_base > 0 ? a_.rope_base : 10000.f, rgam = a_.larope_gamma > 0 ? a_.larope_gamma : 10.f;
+    const bool prerot = rope_mode >= 0 && (rope_mode & 0x100) != 0;  // test hook: rotate the keys in a separate pass first
+    if (prerot) rope_mode &= 0xFF;
+    if (prerot) launch_rope_rows(s_, dtype, const_cast<void*>(pk), C, B, Lk, dkl, 1, 0, H, dh, rope_mode, rbase, rgam);
+    launch_attention(s_, dtype, pq, C, pk, pv, C, dO, C, B, Lq, Lk, H, dh, dql, dkl, rope_mode, rbase, rgam, prerot);
     if (dtype == BF16) launch_bf16_to_f32(s_, static_cast<const uint16_t*>(dO), (int64_t)nq, dO32);
     STN_HIP(hipMemcpyAsync(o, dtype == BF16 ? dO32 : static_cast<float*>(dO), nq * 4, hipMemcpyDeviceToHost, s_));
     sync();

@@ -87,7 +87,8 @@ class Engine {
     // emits text_emb as NCL fp32 [B,Ce,Lt] (if ncl) and/or as rows [B*Lt][Ce] in the act dtype (if rows)
     void text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl, void* rows);
     struct VeCtx { void* text_kv = nullptr; void* style_kv = nullptr; int Lt = 0; };  // step-invariant K/V
-    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl);
+    // tlen: text lengths (the text keys are rotated here, once, with their length-aware positions)
+    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen);
     // time conditioning of `rows` (= B x steps) (current, total) pairs -> tb [rows][main_blocks * C] (fp32, arena)
     float* ve_time_cond_dev(int rows, const float* total_step, const float* current_step);
     // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
@@ -179,8 +180,9 @@ class Engine {
     void* act_alloc(int64_t n) { return ar_.alloc(act_bytes(n)); }
     float* f32_alloc(int64_t n) { return static_cast<float*>(ar_.alloc((size_t)n * 4)); }
     void gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e);
+    // rowvec (optional, [B][rv_ld]): added to every row of sequence b in the same residual epilogue (time conditioning)
     void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
-                  const int* conv_len = nullptr);
+                  const int* conv_len = nullptr, const float* rowvec = nullptr, int rv_ld = 0);
     void attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
                     const int* klen, int rope_mode, bool self);
     void* to_act(const float* src, int64_t n);

@@ -32,6 +32,8 @@ struct Epilogue {
     int L = 1;                   // rows per sequence (row m -> b = m / L, t = m % L)
     const float* aux = nullptr;  // EPI_EULER_T: previous latent [B,N,L]
     const float* row_scale = nullptr; // EPI_EULER_T: per-b scale (dt)
+    const float* rowvec = nullptr;    // EPI_RESID: per-sequence vector [B][rv_ld] added to every row of sequence b (time
+    int rv_ld = 0;                    //            conditioning): resid = (resid + gamma*(acc+bias) + rowvec[b]) * keep
 };
 
 // A: [M][lda] (dtype), W: [N][ldw] (same dtype), K % 8 == 0 (bf16) / K % 4 == 0 (f32), 16-byte aligned rows.
@@ -52,9 +54,16 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
 // fused attention core: softmax(rope(q) rope(k)^T / sqrt(dh)) v, per (b, head).
 // q [B*Lq][ldq], k/v [B*Lk][ldk] (act dtype); o [B*Lq][ldo] (act dtype).
 // rope_mode: -1 none, 0 position index, 1 length-aware (gamma * t / len).
+// k_rotated: the keys already carry their rotation (launch_rope_rows ran on them once) — only q is rotated here.
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
-                      float rope_base, float rope_gamma);
+                      float rope_base, float rope_gamma, bool k_rotated = false);
+// in-place RoPE of `groups` key blocks per row: element (row b*L+t, column g*group_stride + h*dh + i) for t < len[b]
+// (len null: all rows).  Keys that are reused by many attention launches (the vector estimator's text keys: every
+// block of every Euler step) are rotated once here instead of at every launch.  Same arithmetic as the attention
+// kernels' staging (fp32 rotation, one rounding to the storage dtype).
+void launch_rope_rows(hipStream_t s, int dtype, void* x, int ld, int B, int L, const int* len, int groups, int group_stride,
+                      int H, int dh, int rope_mode, float rope_base, float rope_gamma);
 
 // embedding gather: x[b*L+t][:] = (t < len[b] && 0 <= id < vocab) ? emb[id][:] : 0     (fp32 out)
 void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab, int B, int L, int C, const int* len,

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
                                                    const T* __restrict__ v, int ldk, T* __restrict__ o, int ldo, int Lq,
                                                    int Lk, int dh, const int* __restrict__ qlen,
                                                    const int* __restrict__ klen, int rope_mode, float log_base,
-                                                   float gamma) {
+                                                   float gamma, int k_rot) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ds = dh + 1;
     float* Qs = lds;               // [AQ][ds]
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
 
     for (int k0 = 0; k0 < nk; k0 += AK) {
         __syncthreads();  // previous tile fully consumed (and Qs visible on the first pass)
-        stage_rows<T>(k + h * dh, ldk, (int64_t)b * Lk, k0, AK, nk, dh, ds, Ks, rope_mode, log_base, gamma, nk, 1.f);
+        stage_rows<T>(k + h * dh, ldk, (int64_t)b * Lk, k0, AK, nk, dh, ds, Ks, k_rot ? -1 : rope_mode, log_base, gamma, nk, 1.f);
         stage_rows<T>(v + h * dh, ldk, (int64_t)b * Lk, k0, AK, nk, dh, ds, Vs, -1, 0.f, 0.f, 1, 1.f);
         __syncthreads();
         float s[8];
@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                                                         int ldk, uint16_t* __restrict__ o, int ldo, int Lq, int Lk,
                                                         int lk_pad, const int* __restrict__ qlen,
                                                         const int* __restrict__ klen, int rope_mode, float log_base,
-                                                        float gamma) {
+                                                        float gamma, int k_rot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float inv_rev[DH / 2];  // rotation frequency of pair i in REVOLUTIONS per position unit (v_sin/v_cos input)
     constexpr int QS = DH * 2 + 16;  // bytes per Q / K row
     const int VS = lk_pad * 2 + 8;   // bytes per V^T row
     unsigned char* Qs = lds_raw;
@@ -183,7 +184,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     constexpr int HD2 = DH / 2;
     const float qmul = rsqrtf((float)DH) * 1.44269504088896340736f;
 
-    // ---- stage Q and K (RoPE in fp32, stored bf16) -----------------------------------------------------
+    // ---- stage Q and K (RoPE in fp32, stored bf16): 8 pairs per thread-iteration, 16-byte loads and LDS stores ---------
+    if (rope_mode >= 0) {
+        for (int i = tid; i < HD2; i += 256) inv_rev[i] = __expf(-log_base * (float)(2 * i) / (float)DH) * 0.15915494309189535f;
+        __syncthreads();
+    }
+    constexpr int CH = HD2 / 8;  // 16-byte chunks per half row
     for (int pass = 0; pass < 2; ++pass) {
         const uint16_t* src = pass == 0 ? q + h * DH : k + h * DH;
         const int ld = pass == 0 ? ldq : ldk;
@@ -191,28 +197,45 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
         const int pos0 = pass == 0 ? q0 : 0, rows = pass == 0 ? 128 : lk_pad, limit = pass == 0 ? Lq : nk;
         const int seq_len = pass == 0 ? nq : nk;
         const float mul = pass == 0 ? qmul : 1.f;
+        const bool rot = rope_mode >= 0 && !(pass == 1 && k_rot);
+        const float pscale = rope_mode == 1 ? gamma / (float)(seq_len > 0 ? seq_len : 1) : 1.f;
         unsigned char* dst = pass == 0 ? Qs : Ks;
-        for (int idx = tid; idx < rows * HD2; idx += 256) {
-            const int r = idx / HD2, i = idx - r * HD2;
+        for (int idx = tid; idx < rows * CH; idx += 256) {
+            const int r = idx / CH, c = idx - r * CH;
             const int pos = pos0 + r;
-            float x0 = 0.f, x1 = 0.f;
+            u32x4_t w0 = {0u, 0u, 0u, 0u}, w1 = w0;
             if (pos < limit) {
-                const uint16_t* p = src + (seq_base + pos) * ld;
-                x0 = __uint_as_float(((unsigned)p[i]) << 16);
-                x1 = __uint_as_float(((unsigned)p[i + HD2]) << 16);
-                if (rope_mode >= 0) {
-                    const float pp = rope_mode == 1 ? gamma * (float)pos / (float)(seq_len > 0 ? seq_len : 1) : (float)pos;
-                    const float inv = expf(-log_base * (float)(2 * i) / (float)DH);
-                    float sn, cs;
-                    sincosf(pp * inv, &sn, &cs);
-                    const float a0 = x0, a1 = x1;
-                    x0 = a0 * cs - a1 * sn;
-                    x1 = a1 * cs + a0 * sn;
-                }
+                const uint16_t* p = src + (seq_base + pos) * ld + c * 8;
+                w0 = *reinterpret_cast<const u32x4_t*>(p);
+                w1 = *reinterpret_cast<const u32x4_t*>(p + HD2);
             }
-            uint16_t* row = reinterpret_cast<uint16_t*>(dst + r * QS);
-            row[i] = (uint16_t)pack_bf16x2(x0 * mul, 0.f);
-            row[i + HD2] = (uint16_t)pack_bf16x2(x1 * mul, 0.f);
+            u32x4_t o0, o1;
+            if (rot || mul != 1.f) {
+                const float pp = (float)pos * pscale;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    float a0[2] = {__uint_as_float(w0[e2] << 16), __uint_as_float(w0[e2] & 0xFFFF0000u)};
+                    float a1[2] = {__uint_as_float(w1[e2] << 16), __uint_as_float(w1[e2] & 0xFFFF0000u)};
+                    float y0[2], y1[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float cs = 1.f, sn = 0.f;
+                        if (rot) {
+                            const float rev = __builtin_amdgcn_fractf(pp * inv_rev[c * 8 + 2 * e2 + u]);
+                            sn = __builtin_amdgcn_sinf(rev);
+                            cs = __builtin_amdgcn_cosf(rev);
+                        }
+                        y0[u] = (a0[u] * cs - a1[u] * sn) * mul;
+                        y1[u] = (a1[u] * cs + a0[u] * sn) * mul;
+                    }
+                    o0[e2] = pack_bf16x2(y0[0], y0[1]);
+                    o1[e2] = pack_bf16x2(y1[0], y1[1]);
+                }
+            } else {
+                o0 = w0; o1 = w1;
+            }
+            *reinterpret_cast<u32x4_t*>(dst + r * QS + c * 16) = o0;
+            *reinterpret_cast<u32x4_t*>(dst + r * QS + HD2 * 2 + c * 16) = o1;
         }
     }
     // ---- stage V transposed ------------------------------------------------------------------------------
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 template <int DH>
 static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
                              uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int lk_pad, size_t lds, const int* qlen,
-                             const int* klen, int rope_mode, float log_base, float gamma) {
+                             const int* klen, int rope_mode, float log_base, float gamma, int k_rot) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -323,24 +346,25 @@ static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const ui
     }
     const dim3 grid((Lq + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
-                       rope_mode, log_base, gamma);
+                       rope_mode, log_base, gamma, k_rot);
 }
 
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
-                      float rope_base, float rope_gamma) {
+                      float rope_base, float rope_gamma, bool k_rotated) {
     if (B == 0 || Lq == 0) return;
     if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
-    if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15)) {
+    if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
+        !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
         const int lk_pad = (Lk + 31) & ~31;
         const size_t need = (size_t)128 * (dh * 2 + 16) + (size_t)lk_pad * (dh * 2 + 16) + (size_t)dh * (lk_pad * 2 + 8);
         if (need <= 150 * 1024) {
             const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
             uint16_t* o16 = static_cast<uint16_t*>(o);
             const float lb = logf(rope_base);
-            if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma);
-            else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma);
-            else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma);
+            if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated);
+            else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated);
+            else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated);
             return;
         }
     }
@@ -357,11 +381,50 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (dtype == BF16)
         hipLaunchKernelGGL(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
                            static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), ldk, static_cast<uint16_t*>(o), ldo,
-                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma);
+                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated);
     else
         hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(q), ldq,
                            static_cast<const float*>(k), static_cast<const float*>(v), ldk, static_cast<float*>(o), ldo, Lq, Lk,
-                           dh, qlen, klen, rope_mode, log_base, rope_gamma);
+                           dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-time key rotation (see kernels.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_rows_kernel(T* __restrict__ x, int ld, int L, const int* __restrict__ len, int groups, int group_stride,
+                                 int H, int dh, int rope_mode, float log_base, float gamma, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B*L][groups][H][dh/2]
+    if (idx >= n) return;
+    const int hd2 = dh >> 1;
+    const int i = (int)(idx % hd2);
+    int64_t r = idx / hd2;
+    const int h = (int)(r % H); r /= H;
+    const int g = (int)(r % groups); r /= groups;
+    const int pos = (int)(r % L), b = (int)(r / L);
+    const int nb = len ? min(len[b], L) : L;
+    if (pos >= nb) return;
+    T* p = x + r * ld + (int64_t)g * group_stride + h * dh;
+    const float a0 = ld_act(p + i), a1 = ld_act(p + i + hd2);
+    const float pp = rope_mode == 1 ? gamma * (float)pos / (float)(nb > 0 ? nb : 1) : (float)pos;
+    const float inv = expf(-log_base * (float)(2 * i) / (float)dh);
+    float sn, cs;
+    sincosf(pp * inv, &sn, &cs);
+    st_act(p + i, a0 * cs - a1 * sn);
+    st_act(p + i + hd2, a1 * cs + a0 * sn);
+}
+
+void launch_rope_rows(hipStream_t s, int dtype, void* x, int ld, int B, int L, const int* len, int groups, int group_stride,
+                      int H, int dh, int rope_mode, float rope_base, float rope_gamma) {
+    const int64_t n = (int64_t)B * L * groups * H * (dh / 2);
+    if (n == 0 || rope_mode < 0) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == BF16)
+        hipLaunchKernelGGL(rope_rows_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<uint16_t*>(x), ld, L, len, groups,
+                           group_stride, H, dh, rope_mode, logf(rope_base), rope_gamma, n);
+    else
+        hipLaunchKernelGGL(rope_rows_kernel<float>, grid, dim3(256), 0, s, static_cast<float*>(x), ld, L, len, groups, group_stride,
+                           H, dh, rope_mode, logf(rope_base), rope_gamma, n);
 }
 
 }  // namespace stn

@@ -118,7 +118,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2]
         bias[ni] = (ok && e.bias) ? e.bias[ncol[ni]] : 0.f;
         gam[ni] = (ok && e.gamma) ? e.gamma[ncol[ni]] : 1.f;
     }
-    const bool need_bt = (e.len != nullptr) || MODE >= EPI_EULER_T;
+    const bool need_bt = (e.len != nullptr) || MODE >= EPI_EULER_T || (MODE == EPI_RESID && e.rowvec != nullptr);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -144,7 +144,8 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2]
                     else reinterpret_cast<float*>(e.out)[o] = r;
                 } else if (MODE == EPI_RESID) {
                     const size_t o = (size_t)m * e.ldo + n;
-                    e.resid[o] = (e.resid[o] + gam[ni] * v) * keep;
+                    const float rv = e.rowvec ? e.rowvec[(size_t)b * e.rv_ld + n] : 0.f;
+                    e.resid[o] = (e.resid[o] + gam[ni] * v + rv) * keep;
                 } else if (MODE == EPI_EULER_T) {
                     const size_t o = ((size_t)b * N + n) * e.L + t;
                     reinterpret_cast<float*>(e.out)[o] = keep != 0.f ? (e.aux[o] + v * e.row_scale[b]) : 0.f;
@@ -472,7 +473,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
         const int m = m0 + row;
         if (m >= M) continue;
         float keep = 1.f;
-        if (e.len) { const int b = m / e.L; if (m - b * e.L >= e.len[b]) keep = 0.f; }
+        const int b = (e.len || (MODE == EPI_RESID && e.rowvec)) ? m / e.L : 0;
+        if (e.len && m - b * e.L >= e.len[b]) keep = 0.f;
         const float4 v0 = *reinterpret_cast<const float4*>(S + row * BN + c8 * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(S + row * BN + c8 * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -495,8 +497,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
             float* rp = e.resid + o;
             const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
             const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+            if (e.rowvec) { const float* tp = e.rowvec + (size_t)b * e.rv_ld + n; t0 = *reinterpret_cast<const float4*>(tp); t1 = *reinterpret_cast<const float4*>(tp + 4); }
+            const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j])) * keep;
+            for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j]) + tv[j]) * keep;
             *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(rp + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
@@ -692,6 +697,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
         bool ok[ITER];
         float keep[ITER];
         size_t off[ITER];
+        int bq[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int srow = rbase + it * ROWS_PER_IT;
@@ -699,7 +705,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
             ok[it] = ncol_ok && m < M;
             keep[it] = 1.f;
             off[it] = (size_t)m * e.ldo + n;
-            if (ok[it] && e.len) { const int b = m / e.L; if (m - b * e.L >= e.len[b]) keep[it] = 0.f; }
+            bq[it] = 0;
+            if (ok[it] && (e.len || (MODE == EPI_RESID && e.rowvec))) {
+                const int b = m / e.L;
+                bq[it] = b;
+                if (e.len && m - b * e.L >= e.len[b]) keep[it] = 0.f;
+            }
             if (MODE == EPI_RESID) {
                 r0[it] = make_float4(0.f, 0.f, 0.f, 0.f); r1[it] = r0[it];
                 if (ok[it]) { r0[it] = *reinterpret_cast<const float4*>(e.resid + off[it]); r1[it] = *reinterpret_cast<const float4*>(e.resid + off[it] + 4); }
@@ -737,8 +748,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
                 }
             } else {  // EPI_RESID
                 const float r[8] = {r0[it].x, r0[it].y, r0[it].z, r0[it].w, r1[it].x, r1[it].y, r1[it].z, r1[it].w};
+                if (e.rowvec) {  // wave-uniform branch; the vector is a few KB shared by ~L rows: L1/L2 hits
+                    const float* tp = e.rowvec + (size_t)bq[it] * e.rv_ld + n;
+                    const float4 t0 = *reinterpret_cast<const float4*>(tp), t1 = *reinterpret_cast<const float4*>(tp + 4);
+                    const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j])) * keep[it];
+                    for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j]) + tv[j]) * keep[it];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (r[j] + gam[j] * (v[j] + bias[j])) * keep[it];
+                }
                 float* rp = e.resid + off[it];
                 *reinterpret_cast<float4*>(rp) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(rp + 4) = make_float4(v[4], v[5], v[6], v[7]);
