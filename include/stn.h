@@ -134,6 +134,10 @@ int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A /*
                 const float* bias_or_null, int act /*0 none,1 gelu,2 silu*/, float* out /*[M,N]*/);
 /* device-resident timing of one GEMM shape on random operands; mode 0 = bias+GELU store, 1 = residual epilogue */
 int stn_op_gemm_bench(stn_handle* h, int dtype, int M, int N, int K, int mode, int iters, double* avg_ms);
+/* diagnostics: shader-clock phase stamps of ONE launch of the tiled GEMM kernel on this shape (mode as above).  out6 = mean
+ * cycles to the first landed stage, in the K loop, in the epilogue; span of the whole grid; spread of workgroup entry times;
+ * number of workgroups.  Cycles of the s_memtime counter (100 MHz on gfx950: 1 tick = 10 ns). */
+int stn_op_gemm_phases(stn_handle* h, int dtype, int M, int N, int K, int mode, double* out6);
 int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x,
                      const float* w /*[C,k]*/, const float* bias, const float* ln_g, const float* ln_b, float* y);
 /* same with per-sequence valid lengths (taps at t >= seqlen[b] read as zero, rows t >= seqlen[b] come back as zeros) */

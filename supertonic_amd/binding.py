@@ -80,6 +80,7 @@ def load():
                                   ctypes.POINTER(ctypes.c_double)]
     L.stn_op_gemm.argtypes = [vp, ci, ci, ci, ci, _f32p, _f32p, vp, ci, _f32p]
     L.stn_op_gemm_bench.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    L.stn_op_gemm_phases.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     L.stn_op_dwconv_ln.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     L.stn_op_dwconv_ln_ragged.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p]
     L.stn_op_attention.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, vp, vp, ci, _f32p]
@@ -304,6 +305,11 @@ class Engine:
         self._ck(self._lib.stn_op_gemm_bench(self._h, self.dtype if dtype is None else _DTYPES[dtype], M, N, K, mode,
                                              iters, ctypes.byref(ms)))
         return ms.value
+
+    def op_gemm_phases(self, M, N, K, mode=0, dtype=None):
+        out = (ctypes.c_double * 6)()
+        self._ck(self._lib.stn_op_gemm_phases(self._h, self.dtype if dtype is None else _DTYPES[dtype], M, N, K, mode, out))
+        return dict(first_stage=out[0], k_loop=out[1], epilogue=out[2], grid_span=out[3], entry_spread=out[4], workgroups=int(out[5]))
 
     def op_dwconv_ln(self, x, w, bias, g, b, dil, dtype=None, seqlen=None):
         B, L, C = x.shape

@@ -304,6 +304,11 @@ int stn_op_gemm_bench(stn_handle* h, int dtype, int M, int N, int K, int mode, i
                  need(K % (dtype == STN_DTYPE_BF16 ? 8 : 4) == 0, "K must be a multiple of 8 (bf16) / 4 (f32)");
                  *avg_ms = h->eng->op_gemm_bench(dtype, M, N, K, mode, iters); })
 }
+int stn_op_gemm_phases(stn_handle* h, int dtype, int M, int N, int K, int mode, double* out6) {
+    STN_TRY(h, { need(M > 0 && N > 0 && K > 0 && out6, "stn_op_gemm_phases: bad argument");
+                 need(K % (dtype == STN_DTYPE_BF16 ? 8 : 4) == 0, "K must be a multiple of 8 (bf16) / 4 (f32)");
+                 h->eng->op_gemm_phases(dtype, M, N, K, mode, out6); })
+}
 int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w,
                      const float* bias, const float* g, const float* b, float* y) {
     STN_TRY(h, { need(B > 0 && L > 0 && C > 0 && C % 4 == 0 && C <= 1024 && k > 0 && (k & 1) && dil > 0 && x && w && bias && g && b && y,

@@ -1133,6 +1133,53 @@ double Engine::op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters
     return (double)ms / iters;
 }
 
+void Engine::op_gemm_phases(int dtype, int M, int N, int K, int mode, double* out6) {
+    STN_HIP(hipSetDevice(device_));
+    ar_.reset();
+    const size_t esz = dtype == BF16 ? 2 : 4;
+    float* tmp = f32_alloc((size_t)std::max((size_t)M * K, (size_t)N * K));
+    void* A = ar_.alloc((size_t)M * K * esz);
+    void* Wt = ar_.alloc((size_t)N * K * esz);
+    launch_randn_masked(s_, 11, nullptr, 1, 1, (int)std::min<size_t>((size_t)M * K, 1u << 30), nullptr, tmp);
+    launch_cast(s_, dtype, tmp, (int64_t)M * K, A);
+    launch_randn_masked(s_, 12, nullptr, 1, 1, (int)std::min<size_t>((size_t)N * K, 1u << 30), nullptr, tmp);
+    launch_scale(s_, tmp, (int)std::min<size_t>((size_t)N * K, 1u << 30), 1.0f / std::sqrt((float)K));
+    launch_cast(s_, dtype, tmp, (int64_t)N * K, Wt);
+    float* bias = f32_alloc(N);
+    float* gamma = f32_alloc(N);
+    launch_fill(s_, bias, N, 0.01f);
+    launch_fill(s_, gamma, N, 0.2f);
+    float* resid = f32_alloc((size_t)M * N);
+    void* out = ar_.alloc((size_t)M * N * 4);
+    STN_HIP(hipMemsetAsync(resid, 0, (size_t)M * N * 4, s_));
+    const size_t max_wg = 1 << 16;
+    unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(max_wg * 4 * 8));
+    Epilogue e;
+    e.bias = bias;
+    if (mode == 1) { e.mode = EPI_RESID; e.resid = resid; e.ldo = N; e.gamma = gamma; }
+    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : (mode >= 100 ? mode : ACT_GELU); e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
+    for (int i = 0; i < 3; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
+    STN_HIP(hipMemsetAsync(ts, 0, max_wg * 4 * 8, s_));
+    e.ts = ts;
+    launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
+    std::vector<unsigned long long> h(max_wg * 4);
+    STN_HIP(hipMemcpyAsync(h.data(), ts, max_wg * 4 * 8, hipMemcpyDeviceToHost, s_));
+    sync();
+    double p0 = 0, p1 = 0, p2 = 0;
+    unsigned long long tmin = ~0ull, tmax_in = 0, tend = 0;
+    size_t n = 0;
+    for (size_t w = 0; w < max_wg; ++w) {
+        const unsigned long long* t = &h[w * 4];
+        if (t[3] == 0) continue;
+        ++n;
+        p0 += (double)(t[1] - t[0]); p1 += (double)(t[2] - t[1]); p2 += (double)(t[3] - t[2]);
+        tmin = std::min(tmin, t[0]); tmax_in = std::max(tmax_in, t[0]); tend = std::max(tend, t[3]);
+    }
+    if (n == 0) throw std::runtime_error("op_gemm_phases: this shape does not run on the tiled kernel");
+    out6[0] = p0 / n; out6[1] = p1 / n; out6[2] = p2 / n;
+    out6[3] = (double)(tend - tmin); out6[4] = (double)(tmax_in - tmin); out6[5] = (double)n;
+}
+
 void Engine::op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out) {
     STN_HIP(hipSetDevice(device_));
     ar_.reset();

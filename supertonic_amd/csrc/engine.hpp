@@ -159,6 +159,9 @@ class Engine {
                       const float* g, const float* b, float* y, const int* seqlen = nullptr /* host [B] */);
     // device-resident timing of one GEMM shape (random operands), HIP events around `iters` launches: avg ms
     double op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters);
+    // per-workgroup phase stamps of one launch of the tiled kernel: out[0..2] = mean cycles of (first stage landed, K loop,
+    // epilogue), out[3] = max over workgroups of (end - earliest entry), out[4] = spread of entry times, out[5] = workgroups
+    void op_gemm_phases(int dtype, int M, int N, int K, int mode, double* out6);
     void op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out);
 
     Arena& arena() { return ar_; }

@@ -34,6 +34,8 @@ struct Epilogue {
     const float* row_scale = nullptr; // EPI_EULER_T: per-b scale (dt)
     const float* rowvec = nullptr;    // EPI_RESID: per-sequence vector [B][rv_ld] added to every row of sequence b (time
     int rv_ld = 0;                    //            conditioning): resid = (resid + gamma*(acc+bias) + rowvec[b]) * keep
+    unsigned long long* ts = nullptr; // diagnostics (tiled kernels): 4 shader-clock stamps per workgroup — entry, first
+                                      // stage landed, K-loop done, epilogue done (stn_op_gemm_phases)
 };
 
 // A: [M][lda] (dtype), W: [N][ldw] (same dtype), K % 8 == 0 (bf16) / K % 4 == 0 (f32), 16-byte aligned rows.

@@ -567,6 +567,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * BM_, n0 = (tile % tiles_n) * BN_;
+    unsigned long long t_in = 0, t_first = 0, t_loop = 0;
+    if (e.ts) t_in = __builtin_readcyclecounter();
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A + (size_t)m0 * lda * ESZ, m0 < M ? (size_t)(M - m0) * lda * ESZ : 0);
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W + (size_t)n0 * ldw * ESZ, n0 < N ? (size_t)(N - n0) * ldw * ESZ : 0);
@@ -611,6 +613,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     for (int kt = 0; kt < nk; ++kt) {
         wait_stage<PER, NSTAGE - 2>(nk - 1 - kt);
         __builtin_amdgcn_s_barrier();
+        if (e.ts && kt == 0) t_first = __builtin_readcyclecounter();
         const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
         const unsigned char* sb = sa + BM_ * ROWB;
         if constexpr (ESZ == 2) {
@@ -668,6 +671,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
         }
     }
 #undef STN_ISSUE
+    if (e.ts) t_loop = __builtin_readcyclecounter();
 
     // ---- epilogue: TM passes over [WM*32][BN] fp32 slabs --------------------------------------------------
     // A thread keeps ONE 8-column group for the whole epilogue (NTHR is a multiple of BN/8), so bias / layer-scale
@@ -763,6 +767,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
                 *reinterpret_cast<float4*>(rp + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
         }
+    }
+    if (e.ts && tid == 0) {
+        // the stores above are fire-and-forget: wait for them so the last stamp covers the epilogue's memory time too
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* tp = e.ts + (size_t)blockIdx.x * 4;
+        tp[0] = t_in; tp[1] = t_first; tp[2] = t_loop; tp[3] = __builtin_readcyclecounter();
     }
 }
 
