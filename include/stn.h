@@ -118,6 +118,9 @@ int stn_set_stream(stn_handle* h, void* hip_stream);
 /* device->device copy of the finished waveform rows [B][W] into dst (row stride dst_stride floats >= W), enqueued
  * on the handle's stream */
 int stn_batch_copy_wav_device(stn_handle* h, void* dst_device, int64_t dst_stride);
+/* same as 16-bit PCM (the conversion of writeWavFile, cpp/helper.cpp:986-987), e.g. straight into an RCCL gather payload:
+ * half the bytes over xGMI; dst_stride in samples */
+int stn_batch_copy_pcm16_device(stn_handle* h, void* dst_device, int64_t dst_stride);
 
 /* ---- measurement: HIP-event timing of kernel families on the engine's own stream ------------------- */
 int stn_profile_enable(stn_handle* h, int on);

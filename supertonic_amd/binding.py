@@ -71,6 +71,7 @@ def load():
     L.stn_sync.argtypes = [vp]
     L.stn_set_stream.argtypes = [vp, vp]
     L.stn_batch_copy_wav_device.argtypes = [vp, vp, ctypes.c_int64]
+    L.stn_batch_copy_pcm16_device.argtypes = [vp, vp, ctypes.c_int64]
     L.stn_profile_filter.argtypes = [vp, ctypes.c_char_p]
     L.stn_profile_enable.argtypes = [vp, ci]
     L.stn_profile_reset.argtypes = [vp]
@@ -255,6 +256,9 @@ class Engine:
     def set_stream(self, hip_stream_ptr):
         """Enqueue on a caller-owned HIP stream (int pointer, e.g. torch.cuda.current_stream().cuda_stream)."""
         self._ck(self._lib.stn_set_stream(self._h, hip_stream_ptr))
+
+    def batch_copy_pcm16_device(self, dst_ptr, dst_stride):
+        self._ck(self._lib.stn_batch_copy_pcm16_device(self._h, dst_ptr, dst_stride))
 
     def batch_copy_wav_device(self, dst_ptr, dst_stride):
         self._ck(self._lib.stn_batch_copy_wav_device(self._h, dst_ptr, dst_stride))

@@ -271,6 +271,9 @@ int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr) {
 }
 int stn_sync(stn_handle* h) { STN_TRY(h, { h->eng->sync(); }) }
 int stn_set_stream(stn_handle* h, void* hip_stream) { STN_TRY(h, { h->eng->set_stream(static_cast<hipStream_t>(hip_stream)); }) }
+int stn_batch_copy_pcm16_device(stn_handle* h, void* dst, int64_t stride) {
+    STN_TRY(h, { need(dst != nullptr, "dst is null"); h->eng->batch_copy_pcm16_device(static_cast<int16_t*>(dst), stride); })
+}
 int stn_batch_copy_wav_device(stn_handle* h, void* dst, int64_t stride) {
     STN_TRY(h, { need(dst != nullptr, "dst is null"); h->eng->batch_copy_wav_device(static_cast<float*>(dst), stride); })
 }

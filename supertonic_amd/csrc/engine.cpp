@@ -982,6 +982,7 @@ void Engine::enqueue_after_duration(int total_step) {
         vlen = v;
     }
     vocoder_dev(B, L, b.xt[cur], b.wav, vlen);
+    STN_HIP(hipGetLastError());  // a kernel launch that was rejected (bad configuration) must not pass silently
 }
 
 void Engine::batch_fetch(float* wav, size_t wav_capacity, float* duration) {
@@ -1001,7 +1002,7 @@ void Engine::batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration) {
     if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
     if (capacity < nw) throw std::runtime_error("pcm buffer too small: need " + std::to_string(nw) + " samples");
     ensure(b.pcm, b.pcm_cap, nw);
-    launch_f32_to_pcm16(s_, b.wav, (int64_t)nw, b.pcm);
+    launch_f32_to_pcm16(s_, b.wav, (int64_t)b.B, (int)(nw / (size_t)b.B), b.pcm, (int64_t)(nw / (size_t)b.B));
     STN_HIP(hipMemcpyAsync(pcm, b.pcm, nw * 2, hipMemcpyDeviceToHost, s_));
     sync();
     if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
@@ -1012,6 +1013,14 @@ void Engine::batch_copy_wav_device(float* dst, int64_t dst_stride) {
     if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
     if ((size_t)dst_stride < W) throw std::invalid_argument("dst_stride smaller than the waveform length");
     STN_HIP(hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, b.wav, W * 4, W * 4, (size_t)b.B, hipMemcpyDeviceToDevice, s_));
+}
+void Engine::batch_copy_pcm16_device(int16_t* dst, int64_t dst_stride) {
+    STN_HIP(hipSetDevice(device_));
+    Batch& b = bt_;
+    const size_t W = (size_t)b.L * a_.base_chunk_size * a_.chunk_compress_factor;
+    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
+    if ((size_t)dst_stride < W) throw std::invalid_argument("dst_stride smaller than the waveform length");
+    launch_f32_to_pcm16(s_, b.wav, (int64_t)b.B, (int)W, dst, dst_stride);
 }
 void Engine::batch_fetch_latent(float* latent) {
     Batch& b = bt_;

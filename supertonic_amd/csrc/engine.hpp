@@ -144,6 +144,8 @@ class Engine {
     void batch_fetch_latent(float* latent);  // final denoised latent [B,D,L] (tests)
     // device->device: wav rows [B][W] into dst rows of stride dst_stride floats (>= W), on the engine's stream
     void batch_copy_wav_device(float* dst, int64_t dst_stride);
+    // the finished batch as int16 PCM (writeWavFile's conversion) straight into a device buffer, rows dst_stride apart
+    void batch_copy_pcm16_device(int16_t* dst, int64_t dst_stride);
 
     // ---- profiling (hipEvent pairs around launches of one kernel family, on this stream) ----------------
     void profile_enable(bool on) { if (on != prof_on_) profile_reset(); prof_on_ = on; }

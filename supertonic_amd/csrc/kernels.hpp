@@ -5,8 +5,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace stn {
+
+// launch-side HIP calls that must not fail silently (a failed attribute call leaves a sticky error that surfaces in
+// whatever library checks hipGetLastError next)
+inline void stn_check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess) { fprintf(stderr, "stn: %s failed: %s\n", what, hipGetErrorString(e)); abort(); }
+}
+
 
 enum DType : int { F32 = 0, BF16 = 1 };
 enum ActFn : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
@@ -108,6 +117,7 @@ void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out
 // total_step/current_step helper: fill n floats
 void launch_fill(hipStream_t s, float* x, int n, float v);
 // waveform epilogue: pcm[i] = int16(clamp(w[i], -1, 1) * 32767)  (truncation, cpp/helper.cpp:986-987)
-void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t n, int16_t* pcm);
+// rows x W samples -> int16 PCM rows at pcm + row * dst_stride (dst_stride >= W)
+void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t rows, int W, int16_t* pcm, int64_t dst_stride);
 
 }  // namespace stn

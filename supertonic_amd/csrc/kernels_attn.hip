@@ -341,7 +341,8 @@ static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const ui
                              const int* klen, int rope_mode, float log_base, float gamma, int k_rot) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // 150 KiB dynamic (the launcher's own bound) + the kernel's static table stay inside the CU's 160 KiB
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(attn_mfma)");
         attr_set = true;
     }
     const dim3 grid((Lq + 127) / 128, H, B);
@@ -374,8 +375,8 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     const float log_base = logf(rope_base);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f32)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn bf16)");
         attr_set = true;
     }
     if (dtype == BF16)

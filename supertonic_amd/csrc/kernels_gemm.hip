@@ -781,8 +781,8 @@ static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, i
     constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * ESZ;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(gemm_tiled)");
         attr_set = true;
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;

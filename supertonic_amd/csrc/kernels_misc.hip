@@ -722,15 +722,41 @@ void launch_mask_ncl(hipStream_t s, float* x, int B, int D, int L, const int* le
     hipLaunchKernelGGL(mask_ncl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, D, L, n, len);
 }
 
-__global__ void pcm16_kernel(const float* __restrict__ w, int64_t n, int16_t* __restrict__ pcm) {
+// fp32 -> int16 PCM exactly as the reference's writeWavFile (clamp to [-1,1], * 32767, truncation toward zero), 8 samples
+// per thread (two 16-B loads, one 16-B store); rows of W samples may land with a destination stride (gather payloads).
+__global__ void pcm16_kernel(const float* __restrict__ w, int W8, int64_t n8, int16_t* __restrict__ pcm, int64_t dst_stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [rows][W/8]
+    if (i >= n8) return;
+    const int64_t row = i / W8;
+    const int c = (int)(i - row * W8);
+    const float4* src = reinterpret_cast<const float4*>(w) + i * 2;
+    const float4 a = src[0], b = src[1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lo = (int)(fminf(1.0f, fmaxf(-1.0f, v[2 * j])) * 32767.0f);
+        const int hi = (int)(fminf(1.0f, fmaxf(-1.0f, v[2 * j + 1])) * 32767.0f);
+        o[j] = ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+    }
+    *reinterpret_cast<uint4*>(pcm + row * dst_stride + (int64_t)c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__global__ void pcm16_scalar_kernel(const float* __restrict__ w, int W, int64_t n, int16_t* __restrict__ pcm, int64_t dst_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int64_t row = i / W;
     const float c = fminf(1.0f, fmaxf(-1.0f, w[i]));
-    pcm[i] = (int16_t)(int)(c * 32767.0f);  // truncation toward zero, as static_cast<int16_t> in the reference
+    pcm[row * dst_stride + (i - row * W)] = (int16_t)(int)(c * 32767.0f);
 }
-void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t n, int16_t* pcm) {
+void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t rows, int W, int16_t* pcm, int64_t dst_stride) {
+    const int64_t n = rows * W;
     if (n == 0) return;
-    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, pcm);
+    if (W % 8 == 0 && dst_stride % 8 == 0 && !(reinterpret_cast<uintptr_t>(pcm) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15)) {
+        const int64_t n8 = n / 8;
+        hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, W / 8, n8, pcm, dst_stride);
+    } else {
+        hipLaunchKernelGGL(pcm16_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, W, n, pcm, dst_stride);
+    }
 }
 
 }  // namespace stn

@@ -12,10 +12,15 @@ def shard_by_length(lengths, world_size):
 
 
 class GatherPlan:
-    """Shapes of every rank's [B, W] waveform block, exchanged ONCE (tiny all-gather + host read); afterwards
-    `gather` is a single collective per batch with no host synchronisation."""
+    """Shapes of every rank's [B, W] waveform block, exchanged ONCE (tiny all-gather + host read); afterwards a gather is a
+    single collective per batch with no host synchronisation.
 
-    def __init__(self, wav_shape, device, dtype, dst=0):
+    The payload is `slots` buffers of [Bmax, Wmax + tail] in the waveform dtype (float32, or int16 PCM: half the bytes over
+    xGMI); the tail is 16 bytes per row whose first 4 carry the row's duration as float32 bits, so rows stay 16-byte
+    aligned and one collective moves everything.  With two slots the producer fills slot k+1 while slot k is still in
+    flight: `launch(k)` starts the gather without blocking and `wait(k)` orders the caller's stream behind it."""
+
+    def __init__(self, wav_shape, device, dtype, dst=0, slots=1):
         import torch
         import torch.distributed as dist
         self.dst, self.rank, self.world = dst, dist.get_rank(), dist.get_world_size()
@@ -24,24 +29,61 @@ class GatherPlan:
         dist.all_gather(hdrs, hdr)
         self.shapes = [(int(h[0]), int(h[1])) for h in hdrs]
         self.Bm, self.Wm = max(s[0] for s in self.shapes), max(s[1] for s in self.shapes)
-        self.payload = torch.zeros((self.Bm, self.Wm + 1), dtype=dtype, device=device)  # last column carries the duration
-        self.bufs = [torch.empty_like(self.payload) for _ in range(self.world)] if self.rank == dst else None
+        isz = torch.empty((), dtype=dtype).element_size()
+        self.tail = 16 // isz
+        self.Wm = (self.Wm + self.tail - 1) // self.tail * self.tail  # keeps every row (and the tail) 16-byte aligned
+        self.stride = self.Wm + self.tail
+        self.payload = [torch.zeros((self.Bm, self.stride), dtype=dtype, device=device) for _ in range(slots)]
+        self.bufs = [[torch.empty_like(self.payload[0]) for _ in range(self.world)] if self.rank == dst else None
+                     for _ in range(slots)]
+        self.work = [None] * slots
 
-    def gather(self, wav, durations):
-        """wav [B, W], durations [B] on this rank -> on dst: (list of per-rank wav views, list of per-rank durations)."""
+    def _dur_view(self, t):
+        import torch
+        return t[:, self.Wm:].view(torch.float32)[:, 0]
+
+    def wav_ptr(self, k=0):
+        """Device address of slot k's first waveform row (rows are `stride` elements apart): a producer writes in place."""
+        return self.payload[k].data_ptr()
+
+    def set_durations(self, durations, k=0):
+        self._dur_view(self.payload[k])[: durations.shape[0]].copy_(durations, non_blocking=True)
+
+    def launch(self, k=0):
+        """Start the gather of slot k behind the work already queued on the current stream; returns at once."""
         import torch.distributed as dist
-        B, W = wav.shape
-        self.payload[:B, :W].copy_(wav, non_blocking=True)
-        self.payload[:B, self.Wm].copy_(durations, non_blocking=True)
-        dist.gather(self.payload, self.bufs, dst=self.dst)
+        import torch
+        # moved as raw bytes: neither RCCL/NCCL nor gloo has a 16-bit integer type, and a gather does no arithmetic
+        recv = [b.view(torch.uint8) for b in self.bufs[k]] if self.bufs[k] is not None else None
+        self.work[k] = dist.gather(self.payload[k].view(torch.uint8), recv, dst=self.dst, async_op=True)
+
+    def wait(self, k=0):
+        """Order the current stream (on CPU: the caller) behind slot k's gather; a no-op if none is pending."""
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+
+    def result(self, k=0):
+        """On dst, after wait(k): (per-rank wav views, per-rank durations); elsewhere (None, None)."""
         if self.rank != self.dst:
             return None, None
-        return ([b[: s[0], : s[1]] for b, s in zip(self.bufs, self.shapes)],
-                [b[: s[0], self.Wm] for b, s in zip(self.bufs, self.shapes)])
+        return ([b[: s[0], : s[1]] for b, s in zip(self.bufs[k], self.shapes)],
+                [self._dur_view(b)[: s[0]] for b, s in zip(self.bufs[k], self.shapes)])
+
+    def gather(self, wav, durations, k=0):
+        """wav [B, W], durations [B] (float32) on this rank -> on dst: (list of per-rank wav views, list of per-rank durations)."""
+        B, W = wav.shape
+        self.wait(k)
+        self.payload[k][:B, :W].copy_(wav, non_blocking=True)
+        self.set_durations(durations, k)
+        self.launch(k)
+        self.wait(k)
+        return self.result(k)
 
 
 def gather_waveforms(wav, durations, dst=0):
-    """One-shot convenience wrapper: plan + gather.  wav [B, W] and durations [B] (torch tensors on this rank's device) ->
-    on `dst`: lists of per-rank tensors (row counts and W may differ per rank), elsewhere (None, None).
+    """One-shot convenience wrapper: plan + gather.  wav [B, W] (float32 or int16 PCM) and durations [B] (torch tensors on this
+    rank's device) -> on `dst`: lists of per-rank tensors (row counts and W may differ per rank), elsewhere (None, None).
     A gather into one root is bounded by the root's 7 inbound xGMI links, not by a ring."""
-    return GatherPlan(tuple(wav.shape), wav.device, wav.dtype, dst).gather(wav, durations.to(wav.dtype))
+    import torch
+    return GatherPlan(tuple(wav.shape), wav.device, wav.dtype, dst).gather(wav, durations.to(torch.float32))

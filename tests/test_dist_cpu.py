@@ -36,6 +36,15 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        _worker_body(rank, world, q)
+    except Exception as e:  # report instead of leaving the parent to time out on the queue
+        q.put("rank %d: %r" % (rank, e))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_body(rank, world, q):
+    if True:
         B, W = (3, 40) if rank == 0 else (2, 56)  # ragged: row counts and lengths differ per rank
         wav = torch.arange(B * W, dtype=torch.float32).reshape(B, W) + 1000 * rank
         dur = torch.arange(B, dtype=torch.float32) + 10 * rank
@@ -46,6 +55,25 @@ def _worker(rank, world, port, q):
             if rank == 0 and not all(torch.equal(a, b + rep) for a, b in zip(w2, wavs)):
                 q.put(False)
                 return
+        # int16 PCM payload, two slots in flight (what bench.py does on RCCL: fill slot k+1 while slot k travels)
+        pcm = (torch.arange(B * W, dtype=torch.int32).reshape(B, W) % 30000 - 15000 + rank).to(torch.int16)
+        plan2 = GatherPlan((B, W), pcm.device, torch.int16, dst=0, slots=2)
+        for rep in range(4):
+            k = rep & 1
+            plan2.wait(k)
+            plan2.payload[k][:B, :W].copy_(pcm + rep)
+            plan2.set_durations(dur + rep, k)
+            plan2.launch(k)
+        for k in (0, 1):
+            plan2.wait(k)
+            w3, d3 = plan2.result(k)
+            if rank == 0:
+                for r in range(world):
+                    b, w = (3, 40) if r == 0 else (2, 56)
+                    exp = (torch.arange(b * w, dtype=torch.int32).reshape(b, w) % 30000 - 15000 + r).to(torch.int16) + (2 + k)
+                    if not (torch.equal(w3[r], exp) and torch.equal(d3[r], torch.arange(b, dtype=torch.float32) + 10 * r + 2 + k)):
+                        q.put(False)
+                        return
         if rank == 0:
             ok = len(wavs) == world
             for r in range(world):
@@ -55,8 +83,6 @@ def _worker(rank, world, port, q):
             q.put(bool(ok))
         else:
             q.put(wavs is None and durs is None)
-    finally:
-        dist.destroy_process_group()
 
 
 def test_gather_waveforms_gloo_world2():
@@ -69,7 +95,8 @@ def test_gather_waveforms_gloo_world2():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert all(res) and all(p.exitcode == 0 for p in procs)
+    assert all(r is True for r in res), res
+    assert all(p.exitcode == 0 for p in procs)
 
 
 def test_workload_is_deterministic():
