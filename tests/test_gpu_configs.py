@@ -111,3 +111,45 @@ def test_c4_full_size_sharding_invariance(eng_bf16):
         n = lens[i]
         mx, _ = rel_err(lat2[j, :, :n], lat[i, :, :n])
         assert mx < 2e-2, (i, mx)  # different tile shapes / summation orders in bf16, same math
+
+
+def test_c3_full_size_bench_workload_matches_oracle(ref, eng_f32, eng_bf16):
+    """BASELINE.json configs[2] — exactly what bench.py times: 128 ten-word utterances, 5 Euler steps, the 66 M stack, forced
+    durations, utterance-keyed Philox noise.  The fp32 CPU oracle does this batch in ~15 s on the box's cores, so the full
+    size is checked directly rather than through properties: fp32 engine and bf16 engine against the oracle, then
+    run-to-run determinism and eager == hipGraph replay on the bf16 engine."""
+    a = default_arch()
+    texts = workload.utterances(128, 10, seed=1234)
+    ids_all = np.arange(128)
+    tid, mask, sttl, sdp = _prep(texts, ["en"] * 128, ids_all)
+    durs = workload.forced_durations(texts)
+    nz = {}
+
+    def nf(B, D, L):
+        nz["x"] = randn(1234, B, D, L, ids_all.astype(np.int64))
+        return nz["x"]
+
+    rw, rd = ref.synthesize(tid, mask, sttl, sdp, 5, 1.05, nf, duration_override=durs)
+    w32, d32 = eng_f32.synthesize(tid, mask, sttl, sdp, 5, 1.05, noise=nz["x"], duration_override=durs)
+    np.testing.assert_allclose(d32, rd, rtol=1e-6)
+    mx, rms = rel_err(w32, rw)
+    assert mx < 2e-3 and rms < 5e-4, ("f32", mx, rms)
+    # bf16, device-side noise from the same (seed, utterance id) counters as the injected one
+    w16, d16 = eng_bf16.synthesize(tid, mask, sttl, sdp, 5, 1.05, duration_override=durs, noise_seed=1234, utt_ids=ids_all)
+    assert w16.shape == rw.shape == (128, 78 * 3072)
+    mx, rms = rel_err(w16, rw)
+    assert mx < 3e-1 and rms < 5e-2, ("bf16", mx, rms)
+    # per-utterance: no single utterance is an outlier hidden by the batch rms
+    per = [rel_err(w16[i], rw[i])[1] for i in range(128)]
+    assert max(per) < 8e-2, max(per)
+    # exact zeros past every utterance's own latent length are NOT produced by the reference's padded vocoder (zero latent
+    # is signal), but the latent itself is masked exactly
+    lat = eng_bf16.batch_fetch_latent()
+    _, L, lens = host.latent_geometry(d16, 44100, 512, 6, 24)
+    assert L == 78 and all(np.all(lat[i, :, lens[i]:] == 0) for i in range(128))
+    # determinism and replay: the second run captures the graph, the third and fourth replay it
+    r0 = eng_bf16.graph_replays
+    for _ in range(3):
+        w2, _ = eng_bf16.synthesize(tid, mask, sttl, sdp, 5, 1.05, duration_override=durs, noise_seed=1234, utt_ids=ids_all)
+        assert np.array_equal(w2, w16)
+    assert eng_bf16.graph_replays >= r0 + 2
