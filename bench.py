@@ -168,8 +168,9 @@ def main():
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
             if "rocprof_avg_us" in pmc:
                 roof["rocprof_avg_us"] = round(pmc["rocprof_avg_us"], 2)
-                roof["timing_note"] = ("avg_launch_us is a HIP-event span on the engine's stream (includes the ~2-5 us dispatch boundary); "
-                                       "rocprof_avg_us is the kernel's own duration from the committed kernel trace")
+                roof["timing_note"] = ("avg_launch_us: HIP events attached to each launch's dispatch packet on the engine's stream "
+                                       "(hipExtLaunchKernelGGL start/stop = the kernel's own begin/end), live over the timed region; "
+                                       "rocprof_avg_us: the same kernel in the committed rocprofv3 kernel trace")
 
     # ---- the same K steps as hipGraph replays (no event timing possible inside a graph): informational, not `value` --------
     graph = None
@@ -231,7 +232,7 @@ def main():
             tot = sum(v["ms"] for v in fam_stats.values())
             top = sorted(fam_stats.items(), key=lambda kv: -kv[1]["ms"])[:8]
             out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in top}
-            # secondary rooflines from the one fully-profiled warm-up step (HIP-event spans, same caveat as above):
+            # secondary rooflines from the one fully-profiled warm-up step (per-kernel HIP-event spans, as above):
             # GEMM / attention families against dense MFMA peak, the conv / norm families against HBM peak
             other = {}
             for k, v in top:

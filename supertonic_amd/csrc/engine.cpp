@@ -352,13 +352,21 @@ void Engine::prof_begin(const char* tag, double flops, double bytes) {
     };
     sp.a = get();
     sp.b = get();
-    STN_HIP(hipEventRecord(sp.a, s_));
     spans_.push_back(sp);
+    // every span wraps exactly one kernel launch: the events ride on that kernel's dispatch packet (kernels.hpp), so the
+    // span is the kernel's own duration — what rocprofv3's kernel trace reports — not launch-to-launch stream time
+    g_launch_ev.start = sp.a;
+    g_launch_ev.stop = sp.b;
     prof_active_ = true;
 }
 void Engine::prof_end() {
     if (!prof_active_) return;
-    STN_HIP(hipEventRecord(spans_.back().b, s_));
+    if (g_launch_ev.start) {  // nothing was launched (empty problem): drop the span
+        g_launch_ev = LaunchEvents{};
+        ev_pool_.push_back(spans_.back().a);
+        ev_pool_.push_back(spans_.back().b);
+        spans_.pop_back();
+    }
     prof_active_ = false;
 }
 void Engine::profile_reset() {

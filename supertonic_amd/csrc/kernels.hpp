@@ -4,11 +4,28 @@
 // q/k/v/o) are `act_t` = float (STN_F32) or bf16 (STN_BF16).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 namespace stn {
+
+// Kernel-exact timing: when a pair of events is armed here, the NEXT kernel launched through STN_KLAUNCH carries them on
+// its own dispatch packet (hipExtLaunchKernelGGL: start/stop are the kernel's begin/end timestamps, what rocprofv3 reports),
+// instead of being bracketed by hipEventRecord barriers that add the dispatch boundary to the span.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+inline thread_local LaunchEvents g_launch_ev;
+#define STN_KLAUNCH(kernel, grid, block, lds, stream, ...)                                                              \
+    do {                                                                                                                \
+        if (::stn::g_launch_ev.start) {                                                                                 \
+            const ::stn::LaunchEvents ev_ = ::stn::g_launch_ev;                                                         \
+            ::stn::g_launch_ev = ::stn::LaunchEvents{};                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev_.start, ev_.stop, 0, __VA_ARGS__);               \
+        } else {                                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                          \
+        }                                                                                                               \
+    } while (0)
 
 // launch-side HIP calls that must not fail silently (a failed attribute call leaves a sticky error that surfaces in
 // whatever library checks hipGetLastError next)

@@ -346,7 +346,7 @@ static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const ui
         attr_set = true;
     }
     const dim3 grid((Lq + 127) / 128, H, B);
-    hipLaunchKernelGGL(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
+    STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
                        rope_mode, log_base, gamma, k_rot);
 }
 
@@ -380,11 +380,11 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
         attr_set = true;
     }
     if (dtype == BF16)
-        hipLaunchKernelGGL(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
+        STN_KLAUNCH(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
                            static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), ldk, static_cast<uint16_t*>(o), ldo,
                            Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated);
     else
-        hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(q), ldq,
+        STN_KLAUNCH(attn_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(q), ldq,
                            static_cast<const float*>(k), static_cast<const float*>(v), ldk, static_cast<float*>(o), ldo, Lq, Lk,
                            dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated);
 }
@@ -421,10 +421,10 @@ void launch_rope_rows(hipStream_t s, int dtype, void* x, int ld, int B, int L, c
     if (n == 0 || rope_mode < 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
     if (dtype == BF16)
-        hipLaunchKernelGGL(rope_rows_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<uint16_t*>(x), ld, L, len, groups,
+        STN_KLAUNCH(rope_rows_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<uint16_t*>(x), ld, L, len, groups,
                            group_stride, H, dh, rope_mode, logf(rope_base), rope_gamma, n);
     else
-        hipLaunchKernelGGL(rope_rows_kernel<float>, grid, dim3(256), 0, s, static_cast<float*>(x), ld, L, len, groups, group_stride,
+        STN_KLAUNCH(rope_rows_kernel<float>, grid, dim3(256), 0, s, static_cast<float*>(x), ld, L, len, groups, group_stride,
                            H, dh, rope_mode, logf(rope_base), rope_gamma, n);
 }
 

@@ -786,7 +786,7 @@ static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, i
         attr_set = true;
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A, lda,
+    STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A, lda,
                        W, ldw, M, N, K, tiles_n, ntiles, e);
 }
 
@@ -862,16 +862,16 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     }
 #define STN_LAUNCH(MODE)                                                                                         \
     if (ring && vec)                                                                                             \
-        hipLaunchKernelGGL((gemm_bf16_ring_kernel<MODE, true>), dim3(ntiles), dim3(NT), 0, s,                    \
+        STN_KLAUNCH((gemm_bf16_ring_kernel<MODE, true>), dim3(ntiles), dim3(NT), 0, s,                    \
                            static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e); \
     else if (ring)                                                                                               \
-        hipLaunchKernelGGL((gemm_bf16_ring_kernel<MODE, false>), dim3(ntiles), dim3(NT), 0, s,                   \
+        STN_KLAUNCH((gemm_bf16_ring_kernel<MODE, false>), dim3(ntiles), dim3(NT), 0, s,                   \
                            static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e); \
     else if (dtype == BF16)                                                                                      \
-        hipLaunchKernelGGL(gemm_bf16_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const uint16_t*>(A), \
+        STN_KLAUNCH(gemm_bf16_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const uint16_t*>(A), \
                            lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e);              \
     else                                                                                                         \
-        hipLaunchKernelGGL(gemm_f32_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const float*>(A),     \
+        STN_KLAUNCH(gemm_f32_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const float*>(A),     \
                            lda, static_cast<const float*>(W), ldw, M, N, K, tiles_n, ntiles, e);
     switch (e.mode) {
         case EPI_STORE: STN_LAUNCH(EPI_STORE) break;

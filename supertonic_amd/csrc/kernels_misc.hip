@@ -317,7 +317,7 @@ static void launch_dwconv_ln_v3_kr(hipStream_t s, const float* x, int nseq, int 
                                    int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen) {
     const int wps = ((L + R * dil - 1) / (R * dil)) * dil;
     const int64_t nw = (int64_t)nseq * wps;
-    hipLaunchKernelGGL((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
+    STN_KLAUNCH((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
                        dil, wps, g, b, eps, y, seqlen);
 }
 
@@ -345,8 +345,8 @@ static bool launch_dwconv_ln_v2(hipStream_t s, const float* x, int64_t M, int L,
     constexpr int R = 2;
     if (C > 512 || (k != 5 && k != 7)) return false;
     const dim3 grid((unsigned)((M + 4 * R - 1) / (4 * R)));
-    if (k == 5) hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 5, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
-    else hipLaunchKernelGGL((dwconv_ln_v2_kernel<OutT, 7, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+    if (k == 5) STN_KLAUNCH((dwconv_ln_v2_kernel<OutT, 5, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+    else STN_KLAUNCH((dwconv_ln_v2_kernel<OutT, 7, R>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
     return true;
 }
 
@@ -368,10 +368,10 @@ void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L
         return;
     const dim3 grid((unsigned)((M + 3) / 4));
     if (out_dtype == BF16)
-        hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
+        STN_KLAUNCH((dwconv_ln_kernel<uint16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
                            ln_b, eps, static_cast<uint16_t*>(y), seqlen);
     else
-        hipLaunchKernelGGL((dwconv_ln_kernel<float, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b,
+        STN_KLAUNCH((dwconv_ln_kernel<float, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b,
                            eps, static_cast<float*>(y), seqlen);
 }
 
@@ -381,10 +381,10 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
     if (M == 0) return;
     const dim3 grid((unsigned)((M + 3) / 4));
     if (out_dtype == BF16)
-        hipLaunchKernelGGL((dwconv_ln_kernel<uint16_t, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g,
+        STN_KLAUNCH((dwconv_ln_kernel<uint16_t, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g,
                            b, eps, static_cast<uint16_t*>(y), static_cast<const int*>(nullptr));
     else
-        hipLaunchKernelGGL((dwconv_ln_kernel<float, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g, b,
+        STN_KLAUNCH((dwconv_ln_kernel<float, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g, b,
                            eps, static_cast<float*>(y), static_cast<const int*>(nullptr));
 }
 
@@ -408,7 +408,7 @@ __global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __res
 void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab, int B, int L, int C, const int* len,
                   float* x) {
     if (B * L == 0) return;
-    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(64), 0, s, ids, emb, vocab, L, C, len, x);
+    STN_KLAUNCH(embed_kernel, dim3(B * L), dim3(64), 0, s, ids, emb, vocab, L, C, len, x);
 }
 
 __global__ void mask_to_len_kernel(const float* __restrict__ mask, int L, int* __restrict__ len) {
@@ -420,7 +420,7 @@ __global__ void mask_to_len_kernel(const float* __restrict__ mask, int L, int* _
 }
 void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len) {
     if (B == 0) return;
-    hipLaunchKernelGGL(mask_to_len_kernel, dim3(B), dim3(64), 0, s, mask, L, len);
+    STN_KLAUNCH(mask_to_len_kernel, dim3(B), dim3(64), 0, s, mask, L, len);
 }
 
 template <typename OutT>
@@ -438,8 +438,8 @@ void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, in
     const int64_t n = (int64_t)B * ldo * L;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) hipLaunchKernelGGL(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out));
-    else hipLaunchKernelGGL(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out));
+    if (out_dtype == BF16) STN_KLAUNCH(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out));
+    else STN_KLAUNCH(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out));
 }
 
 // 32 x 32 LDS tile transpose: reads of v are coalesced along d, writes of out along t
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict_
 }
 void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out) {
     if (B * D * L == 0) return;
-    hipLaunchKernelGGL(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out);
+    STN_KLAUNCH(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out);
 }
 
 template <typename OutT>
@@ -479,8 +479,8 @@ __global__ void cast_kernel(const float* __restrict__ in, int64_t n, OutT* __res
 void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out) {
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) hipLaunchKernelGGL(cast_kernel<uint16_t>, grid, dim3(256), 0, s, in, n, static_cast<uint16_t*>(out));
-    else hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, s, in, n, static_cast<float*>(out));
+    if (out_dtype == BF16) STN_KLAUNCH(cast_kernel<uint16_t>, grid, dim3(256), 0, s, in, n, static_cast<uint16_t*>(out));
+    else STN_KLAUNCH(cast_kernel<float>, grid, dim3(256), 0, s, in, n, static_cast<float*>(out));
 }
 
 __global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, int ldv, int L, int C4, int64_t n4,
@@ -500,7 +500,7 @@ void launch_add_rowvec(hipStream_t s, float* x, const float* v, int ldv, int B, 
     const int64_t n4 = (int64_t)B * L * (C / 4);
     if (n4 == 0) return;
     if (C % 4 || ldv % 4) { fprintf(stderr, "stn: add_rowvec needs C %% 4 == 0\n"); abort(); }
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, v, ldv, L, C / 4, n4, len);
+    STN_KLAUNCH(add_rowvec_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, v, ldv, L, C / 4, n4, len);
 }
 
 __global__ void time_embed_kernel(const float* __restrict__ cur, const float* __restrict__ tot, int dim, float scale,
@@ -515,7 +515,7 @@ __global__ void time_embed_kernel(const float* __restrict__ cur, const float* __
 }
 void launch_time_embed(hipStream_t s, const float* cur, const float* tot, int B, int dim, float scale, float* te) {
     if (B == 0) return;
-    hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(64), 0, s, cur, tot, dim, scale, te);
+    STN_KLAUNCH(time_embed_kernel, dim3(B), dim3(64), 0, s, cur, tot, dim, scale, te);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,7 +564,7 @@ void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld,
     if (B * T == 0) return;
     const int tiles = (T + VI_FR - 1) / VI_FR;
     const size_t lds = sizeof(float) * (size_t)(VI_FR + k - 1) * ld;
-    hipLaunchKernelGGL(vocoder_in_kernel, dim3(B * tiles), dim3(256), lds, s, latent, L, ld, ccf, w_t, bias, C, k, x, seqlen);
+    STN_KLAUNCH(vocoder_in_kernel, dim3(B * tiles), dim3(256), lds, s, latent, L, ld, ccf, w_t, bias, C, k, x, seqlen);
 }
 
 template <typename OutT>
@@ -593,8 +593,8 @@ void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, in
     const int64_t n = (int64_t)B * L * ccf * kp;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) hipLaunchKernelGGL(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen);
-    else hipLaunchKernelGGL(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols), seqlen);
+    if (out_dtype == BF16) STN_KLAUNCH(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen);
+    else STN_KLAUNCH(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols), seqlen);
 }
 
 template <typename InT>
@@ -609,8 +609,8 @@ __global__ void masked_mean_kernel(const InT* __restrict__ x, int L, int C, cons
 }
 void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled) {
     if (B == 0) return;
-    if (in_dtype == BF16) hipLaunchKernelGGL(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled);
-    else hipLaunchKernelGGL(masked_mean_kernel<float>, dim3(B), dim3(128), 0, s, static_cast<const float*>(x), L, C, len, pooled);
+    if (in_dtype == BF16) STN_KLAUNCH(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled);
+    else STN_KLAUNCH(masked_mean_kernel<float>, dim3(B), dim3(128), 0, s, static_cast<const float*>(x), L, C, len, pooled);
 }
 
 __global__ void softplus_kernel(float* x, int n) {
@@ -618,35 +618,35 @@ __global__ void softplus_kernel(float* x, int n) {
     if (i < n) { const float y = x[i]; x[i] = y > 20.f ? y : log1pf(expf(y)); }
 }
 void launch_softplus(hipStream_t s, float* x, int n) {
-    if (n) hipLaunchKernelGGL(softplus_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
+    if (n) STN_KLAUNCH(softplus_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
 }
 __global__ void scale_kernel(float* x, int n, float mul) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] *= mul;
 }
 void launch_scale(hipStream_t s, float* x, int n, float mul) {
-    if (n) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, mul);
+    if (n) STN_KLAUNCH(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, mul);
 }
 __global__ void reciprocal_kernel(const float* in, int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = 1.0f / in[i];
 }
 void launch_reciprocal(hipStream_t s, const float* in, int n, float* out) {
-    if (n) hipLaunchKernelGGL(reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, out);
+    if (n) STN_KLAUNCH(reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, out);
 }
 __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = bf2f_(in[i]);
 }
 void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out) {
-    if (n) hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+    if (n) STN_KLAUNCH(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
 }
 __global__ void fill_kernel(float* x, int n, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = v;
 }
 void launch_fill(hipStream_t s, float* x, int n, float v) {
-    if (n) hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, v);
+    if (n) STN_KLAUNCH(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -696,7 +696,7 @@ void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, i
                          float* xt, const unsigned long long* seed_dev) {
     const int64_t n4 = (int64_t)B * D * ((L + 3) / 4);
     if (n4 == 0) return;
-    hipLaunchKernelGGL(randn_masked_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (unsigned long long)seed,
+    STN_KLAUNCH(randn_masked_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (unsigned long long)seed,
                        seed_dev, utt_ids, D, L, len, n4, xt);
 }
 
@@ -706,7 +706,7 @@ __global__ void scale_len_kernel(const int* __restrict__ len, int B, int factor,
 }
 void launch_scale_len(hipStream_t s, const int* len, int B, int factor, int* out) {
     if (B == 0) return;
-    hipLaunchKernelGGL(scale_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, factor, out);
+    STN_KLAUNCH(scale_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, factor, out);
 }
 
 __global__ void mask_ncl_kernel(float* __restrict__ x, int D, int L, int64_t n, const int* __restrict__ len) {
@@ -719,7 +719,7 @@ __global__ void mask_ncl_kernel(float* __restrict__ x, int D, int L, int64_t n, 
 void launch_mask_ncl(hipStream_t s, float* x, int B, int D, int L, const int* len) {
     const int64_t n = (int64_t)B * D * L;
     if (n == 0) return;
-    hipLaunchKernelGGL(mask_ncl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, D, L, n, len);
+    STN_KLAUNCH(mask_ncl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, D, L, n, len);
 }
 
 // fp32 -> int16 PCM exactly as the reference's writeWavFile (clamp to [-1,1], * 32767, truncation toward zero), 8 samples
@@ -753,9 +753,9 @@ void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t rows, int W, int
     if (n == 0) return;
     if (W % 8 == 0 && dst_stride % 8 == 0 && !(reinterpret_cast<uintptr_t>(pcm) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15)) {
         const int64_t n8 = n / 8;
-        hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, W / 8, n8, pcm, dst_stride);
+        STN_KLAUNCH(pcm16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, W / 8, n8, pcm, dst_stride);
     } else {
-        hipLaunchKernelGGL(pcm16_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, W, n, pcm, dst_stride);
+        STN_KLAUNCH(pcm16_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, W, n, pcm, dst_stride);
     }
 }
 
