@@ -60,6 +60,7 @@ struct Epilogue {
     const float* row_scale = nullptr; // EPI_EULER_T: per-b scale (dt)
     const float* rowvec = nullptr;    // EPI_RESID: per-sequence vector [B][rv_ld] added to every row of sequence b (time
     int rv_ld = 0;                    //            conditioning): resid = (resid + gamma*(acc+bias) + rowvec[b]) * keep
+    int tr_epilogue = 0;              // tiled kernels, bf16 store: wave-private transposed-image epilogue (set by the launcher)
     unsigned long long* ts = nullptr; // diagnostics (tiled kernels): 4 shader-clock stamps per workgroup — entry, first
                                       // stage landed, K-loop done, epilogue done (stn_op_gemm_phases)
 };

@@ -673,6 +673,75 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
 #undef STN_ISSUE
     if (e.ts) t_loop = __builtin_readcyclecounter();
 
+    // ---- bf16 store epilogue through a wave-private transposed image (gfx950 ds_read_b64_tr_b16) --------------------------
+    // In the accumulator layout a lane holds 4 CONSECUTIVE ROWS of one column per register quad.  After bias + activation
+    // those 4 values are packed to 8 bytes and written with one ds_write_b64 into a [column][row] image of the wave's own
+    // 32x32 subtile (72-byte rows: conflict-free); the hardware transpose read hands each lane 4 consecutive COLUMNS of one
+    // row, two of them make the 16-byte global store.  Against the fp32 slab transpose below: 4 LDS writes per subtile and
+    // lane instead of 16, half the read bytes, and no workgroup barrier — every wave drains its tiles at its own pace.
+    if (MODE == EPI_STORE && ESZ == 2 && e.out_dtype == BF16 && e.len == nullptr && e.tr_epilogue) {
+        constexpr int TSTR = 72, TIMG = 32 * TSTR;  // bytes per image row / per image
+        static_assert(NSTAGE * STAGE >= NW * 2 * TIMG, "transposed images must fit in the ring");
+        typedef short v4s_ __attribute__((ext_vector_type(4)));
+        __syncthreads();  // every wave is done reading the operand ring
+        unsigned char* img0 = smem + wave * (2 * TIMG);
+        const int cl_ = lane & 31, hf_ = lane >> 5;
+        const int G_ = lane >> 4, i16_ = lane & 15, q_ = i16_ >> 2, p_ = i16_ & 3;
+        int buf = 0;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int ncol = n0 + (wn * TN + ni) * 32 + cl_;
+            const float bs = (ncol < N && e.bias) ? e.bias[ncol] : 0.f;
+            const int nst = n0 + (wn * TN + ni) * 32 + 8 * G_;  // first of this lane's 8 output columns
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                unsigned char* img = img0 + buf * TIMG;
+                buf ^= 1;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = acc[mi][ni][i] + bs;
+                if (e.act == ACT_GELU) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = gelu_bf16_f(v[i]);
+                } else if (e.act == ACT_SILU) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = v[i] / (1.0f + expf(-v[i]));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v[4 * g]) | ((unsigned)f2bf(v[4 * g + 1]) << 16);
+                    pk.y = (unsigned)f2bf(v[4 * g + 2]) | ((unsigned)f2bf(v[4 * g + 3]) << 16);
+                    *reinterpret_cast<uint2*>(img + cl_ * TSTR + (8 * g + 4 * hf_) * 2) = pk;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in order per wave; keep the compiler in order too
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // block rows = tile columns 8G+q (and +4), block columns = tile rows 16t + 4p ..; lane i16 receives tile row 16t+i16
+                    const unsigned char* a0 = img + (8 * G_ + q_) * TSTR + (16 * t + 4 * p_) * 2;
+                    const v4s_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_*)(a0));
+                    const v4s_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_*)(a0 + 4 * TSTR));
+                    const int m = m0 + (wm * TM + mi) * 32 + 16 * t + i16_;
+                    if (m < M && nst < N) {
+                        uint4 o;
+                        o.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+                        o.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+                        o.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+                        o.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + (size_t)m * e.ldo + nst) = o;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+        if (e.ts && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            unsigned long long* tp = e.ts + (size_t)blockIdx.x * 4;
+            tp[0] = t_in; tp[1] = t_first; tp[2] = t_loop; tp[3] = __builtin_readcyclecounter();
+        }
+        return;
+    }
+
     // ---- epilogue: TM passes over [WM*32][BN] fp32 slabs --------------------------------------------------
     // A thread keeps ONE 8-column group for the whole epilogue (NTHR is a multiple of BN/8), so bias / layer-scale
     // are loaded once, and the per-pass loop is fully unrolled with its global loads (residual) issued up front.
@@ -811,30 +880,37 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
         if (N >= 256 && t256 >= 200) {
             if (t256 < 512) cfg = 11;                      // one round of tiles: 16 waves shorten the per-tile critical path
-            else if (K <= 512 && t256 >= 1024) cfg = 10;   // short K, many tiles: 2 WGs/CU overlap epilogue with main loop
+            else if (K <= 512 && t256 >= 1024) cfg = 17;   // short K, many tiles: 256x128, 8 waves, 2 WGs/CU (4 % over the 4-wave form)
             else cfg = 1;
         } else if (K % 64 == 0) cfg = M <= 64 ? 12 : 8;
         else return false;
     }
     if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14) && K % 64) return false;
+    static int g_tr = -2;
+    if (g_tr == -2) { const char* c = getenv("STN_GEMM_TR"); g_tr = c ? atoi(c) : 1; }
+    Epilogue et = e;
+    // the transposed-image epilogue stores 64-byte row segments (16 rows per instruction): a win where a CU runs one tile
+    // (-4 % ve.pw1, -15 % te.pw1), a loss where a co-resident workgroup's K loop competes for the vector-memory path (vo.pw1)
+    et.tr_epilogue = g_tr == 2 || (g_tr == 1 && (cfg == 11 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14));
+    const Epilogue& e_ = et;
     switch (cfg) {
-        case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 2: launch_tiled<MODE, 256, 128, 4, 2, 5, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 3: launch_tiled<MODE, 128, 128, 2, 2, 8, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 4: launch_tiled<MODE, 128, 256, 2, 4, 5, 32>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 5: launch_tiled<MODE, 128, 128, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 6: launch_tiled<MODE, 128, 128, 2, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 7: launch_tiled<MODE, 256, 128, 4, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 8: launch_tiled<MODE, 128, 128, 2, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;
-        case 9: launch_tiled<MODE, 128, 256, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;   // 72 KiB: 2 WGs / CU
-        case 10: launch_tiled<MODE, 256, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB: 2 WGs / CU
-        case 11: launch_tiled<MODE, 256, 256, 4, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 16 waves
-        case 12: launch_tiled<MODE, 64, 64, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;    // tiny M
-        case 13: launch_tiled<MODE, 128, 128, 4, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;  // 16 waves, 4 per SIMD
-        case 14: launch_tiled<MODE, 128, 64, 4, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e); return true;   // more tiles for narrow N
-        case 15: launch_tiled<MODE, 128, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 48 KiB: 3 WGs / CU
-        case 16: launch_tiled<MODE, 128, 256, 2, 4, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB, 8 waves: 2 WGs / CU
-        case 17: launch_tiled<MODE, 256, 128, 4, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e); return true;  // 72 KiB, 8 waves: 2 WGs / CU
+        case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 2: launch_tiled<MODE, 256, 128, 4, 2, 5, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 3: launch_tiled<MODE, 128, 128, 2, 2, 8, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 4: launch_tiled<MODE, 128, 256, 2, 4, 5, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 5: launch_tiled<MODE, 128, 128, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 6: launch_tiled<MODE, 128, 128, 2, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 7: launch_tiled<MODE, 256, 128, 4, 2, 3, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 8: launch_tiled<MODE, 128, 128, 2, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;
+        case 9: launch_tiled<MODE, 128, 256, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;   // 72 KiB: 2 WGs / CU
+        case 10: launch_tiled<MODE, 256, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB: 2 WGs / CU
+        case 11: launch_tiled<MODE, 256, 256, 4, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 16 waves
+        case 12: launch_tiled<MODE, 64, 64, 2, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;    // tiny M
+        case 13: launch_tiled<MODE, 128, 128, 4, 4, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 16 waves, 4 per SIMD
+        case 14: launch_tiled<MODE, 128, 64, 4, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;   // more tiles for narrow N
+        case 15: launch_tiled<MODE, 128, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 48 KiB: 3 WGs / CU
+        case 16: launch_tiled<MODE, 128, 256, 2, 4, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB, 8 waves: 2 WGs / CU
+        case 17: launch_tiled<MODE, 256, 128, 4, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB, 8 waves: 2 WGs / CU
         default: return false;
     }
 }
