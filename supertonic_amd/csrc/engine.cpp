@@ -1134,7 +1134,7 @@ double Engine::op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters
     Epilogue e;
     e.bias = bias;
     if (mode == 1) { e.mode = EPI_RESID; e.resid = resid; e.ldo = N; e.gamma = gamma; }
-    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : (mode >= 100 ? mode : ACT_GELU); e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
+    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : ACT_GELU; e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
     for (int i = 0; i < 3; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
     hipEvent_t a, b;
     STN_HIP(hipEventCreate(&a));
@@ -1174,7 +1174,7 @@ void Engine::op_gemm_phases(int dtype, int M, int N, int K, int mode, double* ou
     Epilogue e;
     e.bias = bias;
     if (mode == 1) { e.mode = EPI_RESID; e.resid = resid; e.ldo = N; e.gamma = gamma; }
-    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : (mode >= 100 ? mode : ACT_GELU); e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
+    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : ACT_GELU; e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
     for (int i = 0; i < 3; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
     STN_HIP(hipMemsetAsync(ts, 0, max_wg * 4 * 8, s_));
     e.ts = ts;

@@ -77,15 +77,6 @@ __device__ __forceinline__ void act8(float (&v)[8], const float (&bias)[8], int 
     } else if (act == ACT_GELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j] + bias[j]) * keep;
-    } else if (act == 100) {  // experiments: plain VALU only
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t * fmaf(t * t, -0.1f, 0.5f) * keep; }
-    } else if (act == 101) {  // experiments: one v_exp_f32
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t * __builtin_amdgcn_exp2f(-t * t) * keep; }
-    } else if (act == 102) {  // experiments: one v_rcp_f32
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t * __builtin_amdgcn_rcpf(1.0f + t * t) * keep; }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t / (1.0f + expf(-t)) * keep; }
