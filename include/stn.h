@@ -102,6 +102,10 @@ int stn_set_graph_mode(stn_handle* h, int on);
  * end at its own latent length, so wav[b, :len_b] is what a batch-of-one synthesis of utterance b gives — the mode in which
  * the chunks of a long text (TextToSpeech::call, cpp/helper.cpp:685-722, one _infer per chunk) run as ONE batch. */
 int stn_set_vocoder_mode(stn_handle* h, int length_aware);
+/* Row layout of the vector estimator inside stn_batch_run.  1 (default) = packed: the estimator's activations hold only the
+ * latent frames each utterance owns (sum of lengths rows), 0 = padded [b*L + t] rows with the padding masked to zero after
+ * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
+int stn_set_row_layout(stn_handle* h, int packed);
 int64_t stn_graph_replays(const stn_handle* h);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
 int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);

@@ -61,6 +61,7 @@ def load():
     L.stn_batch_run.argtypes = [vp, ci, cf, cu64]
     L.stn_set_graph_mode.argtypes = [vp, ci]
     L.stn_set_vocoder_mode.argtypes = [vp, ci]
+    L.stn_set_row_layout.argtypes = [vp, ci]
     L.stn_graph_replays.restype = ctypes.c_int64
     L.stn_graph_replays.argtypes = [vp]
     L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
@@ -210,6 +211,10 @@ class Engine:
 
     def set_graph_mode(self, on=True):
         self._ck(self._lib.stn_set_graph_mode(self._h, int(on)))
+
+    def set_packed_rows(self, on=True):
+        """Vector-estimator row layout in batch_run: packed (default, no work on padding) or padded [b*L + t]."""
+        self._ck(self._lib.stn_set_row_layout(self._h, int(bool(on))))
 
     def set_vocoder_mode(self, length_aware):
         """False: the reference's batched vocoder (padding decoded as zero latent). True: every utterance ends at its own length."""

@@ -98,6 +98,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     STN_HIP(hipSetDevice(device));
     STN_HIP(hipStreamCreateWithFlags(&own_s_, hipStreamNonBlocking));
     s_ = own_s_;
+    if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
 
 void Engine::set_stream(hipStream_t s) {
@@ -419,19 +420,20 @@ void* Engine::to_act(const float* src, int64_t n) {
 
 // x <- (x + gamma * pw2(GELU(pw1(LN(dwconv(x)))))) * mask      (in place, x fp32 [B*L][C])
 void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
-                      const int* conv_len, const float* rowvec, int rv_ld) {
-    const int64_t M = (int64_t)B * L;
+                      const int* conv_len, const float* rowvec, int rv_ld, const Ragged* rg) {
+    const int64_t M = rg ? (int64_t)rg->rows : (int64_t)B * L;
     const Arena::Mark mk = ar_.mark();
     void* xn = act_alloc(M * C);
     void* u = act_alloc(M * hid);
     if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (dt_ == BF16 ? 2.0 : 4.0)));
-    launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, conv_len);
+    launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, rg ? len : conv_len, rg ? rg->off : nullptr);
     if (prof_on_) prof_end();
     Epilogue e1;
     e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
     gemm("gemm_pw1_gelu", dt_, xn, C, p.pw1, (int)M, e1);
     Epilogue e2;
-    e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.gamma = p.gamma; e2.len = len; e2.L = L; e2.rowvec = rowvec; e2.rv_ld = rv_ld;
+    e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.gamma = p.gamma; e2.len = rg ? nullptr : len; e2.L = L; e2.rowvec = rowvec; e2.rv_ld = rv_ld;
+    e2.row_b = (rg && rowvec) ? rg->row_b : nullptr;
     gemm("gemm_pw2_resid", dt_, u, hid, p.pw2, (int)M, e2);
     ar_.release(mk);
 }
@@ -590,18 +592,20 @@ float* Engine::ve_time_cond_dev(int rows, const float* total_step, const float* 
 }
 
 void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
-                         const float* total_step, const float* current_step, float* denoised, const float* tb) {
+                         const float* total_step, const float* current_step, float* denoised, const float* tb, const Ragged* rg) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, D = a.latent_dim * a.chunk_compress_factor, nb = a.ve_main_blocks, H = a.ve_heads;
-    const int64_t M = (int64_t)B * L;
+    const int64_t M = rg ? (int64_t)rg->rows : (int64_t)B * L;  // packed: only the frames the utterances own
+    const int* rmask = rg ? nullptr : llen;                     // padded rows are re-zeroed by every residual epilogue
+    const int* roff = rg ? rg->off : nullptr;
     const size_t esz = dt_ == BF16 ? 2 : 4;
     const Arena::Mark mk = ar_.mark();
     const int Dp = (D + 63) / 64 * 64;
     void* z = act_alloc(M * Dp);
-    launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z, Dp);
+    launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z, Dp, llen, roff);
     float* x = f32_alloc(M * C);
-    Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = x; ein.ldo = C; ein.len = llen; ein.L = L;
+    Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = x; ein.ldo = C; ein.len = rmask; ein.L = L;
     gemm("gemm_in", dt_, z, Dp, linear("ve.in_pad"), (int)M, ein);
     if (!tb) tb = ve_time_cond_dev(B, total_step, current_step);
 
@@ -619,9 +623,9 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         void* o = act_alloc(M * C);
         if (prof_on_) prof_begin("attention", 4.0 * M * (double)Lk * C, (double)(M * 2 + (int64_t)B * Lk * 2) * C * esz);
         launch_attention(s_, dt_, qb, C, kp, vp, nb * 2 * C, o, C, B, L, Lk, H, C / H, llen, klen, rope_mode, a.rope_base,
-                         a.larope_gamma, /*k_rotated=*/rope_mode >= 0);
+                         a.larope_gamma, /*k_rotated=*/rope_mode >= 0, roff);
         if (prof_on_) prof_end();
-        Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = llen; eo.L = L;
+        Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = rmask; eo.L = L;
         gemm("gemm_attn_out", dt_, o, C, w.o, (int)M, eo);
         ar_.release(m2);
     };
@@ -632,16 +636,16 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         for (int j = 0; j < a.ve_dilated; ++j) {
             const bool last = j == a.ve_dilated - 1;
             convnext(convnext_w(p + ".dil" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1 << j, llen, nullptr,
-                     last ? tb + (size_t)blk * C : nullptr, nb * C);
+                     last ? tb + (size_t)blk * C : nullptr, nb * C, rg);
         }
-        if (a.ve_dilated == 0) launch_add_rowvec(s_, x, tb + (size_t)blk * C, nb * C, B, L, C, llen);
-        convnext(convnext_w(p + ".cn_a"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
+        if (a.ve_dilated == 0) launch_add_rowvec(s_, x, tb + (size_t)blk * C, nb * C, B, L, C, llen);  // (padded layout only)
+        convnext(convnext_w(p + ".cn_a"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg);
         cross(p + ".text", c.text_kv, blk, c.Lt, tlen, 1);
-        convnext(convnext_w(p + ".cn_b"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
+        convnext(convnext_w(p + ".cn_b"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg);
         cross(p + ".style", c.style_kv, blk, a.n_style_ttl, nullptr, -1);
     }
     for (int j = 0; j < a.ve_tail_blocks; ++j)
-        convnext(convnext_w("ve.tail" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen);
+        convnext(convnext_w("ve.tail" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg);
     void* xn = act_alloc(M * C);
     const LNorm ln = lnorm("ve.out_ln");
     launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
@@ -652,7 +656,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     float* vel = f32_alloc(M * D);
     Epilogue eo; eo.mode = EPI_STORE; eo.out_dtype = F32; eo.out = vel; eo.ldo = D;
     gemm("gemm_out", dt_, xn, C, linear("ve.out"), (int)M, eo);
-    launch_euler_ncl(s_, noisy, vel, dtv, llen, B, D, L, denoised);
+    launch_euler_ncl(s_, noisy, vel, dtv, llen, B, D, L, denoised, roff);
     ar_.release(mk);
 }
 
@@ -912,7 +916,9 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     }
 
     GraphKey key;
-    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.gen = b.gen; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
+    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.gen = b.gen;
+    key.rows = 0;
+    if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
     if (graphable && graph_exec_ && key == graph_key_) {
@@ -975,10 +981,21 @@ void Engine::enqueue_after_duration(int total_step) {
     for (int st = 0; st < total_step; ++st) launch_fill(s_, cur_all + (size_t)st * B, B, (float)st);
     const float* tb_all = ve_time_cond_dev(total_step * B, tot_all, cur_all);
     const size_t tb_stride = (size_t)B * a.ve_main_blocks * a.ve_dim;
+    Ragged rg;
+    const Ragged* rgp = nullptr;
+    if (packed_rows_ok(B)) {  // the estimator works on the frames the utterances own and nothing else
+        rg.rows = 0;
+        for (int v : b.h_llen) rg.rows += v;
+        int* off = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)(B + 1)));
+        int* row_b = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)std::max(rg.rows, 1)));
+        launch_row_map(s_, b.llen, B, off, row_b);
+        rg.off = off; rg.row_b = row_b;
+        rgp = &rg;
+    }
     int cur = 0;
     for (int st = 0; st < total_step; ++st) {
         ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, tot_all + (size_t)st * B, cur_all + (size_t)st * B, b.xt[cur ^ 1],
-                    tb_all + (size_t)st * tb_stride);
+                    tb_all + (size_t)st * tb_stride, rgp);
         cur ^= 1;
     }
     final_xt_ = cur;

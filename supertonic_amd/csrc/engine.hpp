@@ -92,8 +92,12 @@ class Engine {
     // time conditioning of `rows` (= B x steps) (current, total) pairs -> tb [rows][main_blocks * C] (fp32, arena)
     float* ve_time_cond_dev(int rows, const float* total_step, const float* current_step);
     // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
+    // Packed ("ragged") latent rows: utterance b owns rows off[b] .. off[b] + llen[b] and no padding rows exist; `rows` is
+    // their total.  The masked stages are row-independent, so this is an exact optimisation of the padded [b*L + t] layout.
+    struct Ragged { const int* off = nullptr; const int* row_b = nullptr; int rows = 0; };
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
-                     const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr);
+                     const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr,
+                     const Ragged* rg = nullptr);
     // vlen (optional, device [B]): valid vocoder frames per utterance — the length-aware mode (see set_vocoder_mode)
     void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr);
 
@@ -136,6 +140,9 @@ class Engine {
     void set_graph_mode(bool on) { graph_on_ = on; }
     // length-aware vocoder in batch_run: every utterance's frames end at its own length, as in a batch-of-one run
     void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
+    // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
+    void set_packed_rows(bool on) { packed_ve_ = on; }
+    bool packed_rows_ok(int B) const { return packed_ve_ && B <= 1024 && a_.ve_dilated > 0 && dwconv_ln_supports_packed(a_.ve_dim, a_.ve_kernel); }
     long graph_replays() const { return graph_replays_; }
     const Batch& batch() const { return bt_; }
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
@@ -187,7 +194,7 @@ class Engine {
     void gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e);
     // rowvec (optional, [B][rv_ld]): added to every row of sequence b in the same residual epilogue (time conditioning)
     void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
-                  const int* conv_len = nullptr, const float* rowvec = nullptr, int rv_ld = 0);
+                  const int* conv_len = nullptr, const float* rowvec = nullptr, int rv_ld = 0, const Ragged* rg = nullptr);
     void attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
                     const int* klen, int rope_mode, bool self);
     void* to_act(const float* src, int64_t n);
@@ -214,11 +221,12 @@ class Engine {
     std::vector<float> reported_dur_;
     void enqueue_after_duration(int total_step);
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
-        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int rows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && rows == o.rows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
     };
     bool graph_on_ = true;
     bool vo_ragged_ = false;
+    bool packed_ve_ = true;
     GraphKey graph_key_, warm_key_;
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t graph_ = nullptr;

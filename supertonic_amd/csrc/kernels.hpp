@@ -58,6 +58,7 @@ struct Epilogue {
     int L = 1;                   // rows per sequence (row m -> b = m / L, t = m % L)
     const float* aux = nullptr;  // EPI_EULER_T: previous latent [B,N,L]
     const float* row_scale = nullptr; // EPI_EULER_T: per-b scale (dt)
+    const int* row_b = nullptr;       // packed rows: sequence of row m (replaces m / L for rowvec; len must be null then)
     const float* rowvec = nullptr;    // EPI_RESID: per-sequence vector [B][rv_ld] added to every row of sequence b (time
     int rv_ld = 0;                    //            conditioning): resid = (resid + gamma*(acc+bias) + rowvec[b]) * keep
     int tr_epilogue = 0;              // tiled kernels, bf16 store: wave-private transposed-image epilogue (set by the launcher)
@@ -75,7 +76,11 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
 // length-aware mode in which a padded batch reproduces what each sequence would give on its own
 void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L, int C, const float* w_t,
                       const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y,
-                      const int* seqlen = nullptr);
+                      const int* seqlen = nullptr, const int* row_off = nullptr);
+// Packed ("ragged") rows: sequence b owns rows row_off[b] .. row_off[b] + len[b] of x / y and nothing else — no padding rows
+// exist.  row_off has B+1 entries (launch_row_map); supported where dwconv_ln_supports_packed(C, k).
+bool dwconv_ln_supports_packed(int C, int k);
+void launch_row_map(hipStream_t s, const int* len, int B, int* row_off /*[B+1]*/, int* row_b /*[sum len]*/);
 // plain LayerNorm over C: x fp32 -> y act
 void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
                       float eps, void* y);
@@ -86,7 +91,8 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
 // k_rotated: the keys already carry their rotation (launch_rope_rows ran on them once) — only q is rotated here.
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
-                      float rope_base, float rope_gamma, bool k_rotated = false);
+                      float rope_base, float rope_gamma, bool k_rotated = false,
+                      const int* q_off = nullptr /* packed query/output rows: sequence b starts at q_off[b], owns qlen[b] */);
 // in-place RoPE of `groups` key blocks per row: element (row b*L+t, column g*group_stride + h*dh + i) for t < len[b]
 // (len null: all rows).  Keys that are reused by many attention launches (the vector estimator's text keys: every
 // block of every Euler step) are rotated once here instead of at every launch.  Same arithmetic as the attention
@@ -100,9 +106,11 @@ void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab
 // prefix mask [B][L] (float) -> len[B] (count of entries > 0.5)
 void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len);
 // [B][C][L] fp32 -> rows [B*L][ld_out] act (columns C..ld_out-1 are zero-filled: K padding for the GEMM that follows)
-void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out = 0);
+void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out = 0,
+                        const int* len = nullptr, const int* row_off = nullptr /* packed destination rows */);
 // Euler update with the [B*L][D] -> [B][D][L] transpose: out[b][d][t] = t < len[b] ? prev[b][d][t] + v[(b*L+t)*D + d] * dt[b] : 0
-void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out);
+void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out,
+                      const int* row_off = nullptr /* v in packed rows */);
 // fp32 -> act dtype copy (n elements)
 void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out);
 // x[b*L+t][c] += v[b*ldv + c] for t < len[b]

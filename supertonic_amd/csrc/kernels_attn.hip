@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
                                                    const T* __restrict__ v, int ldk, T* __restrict__ o, int ldo, int Lq,
                                                    int Lk, int dh, const int* __restrict__ qlen,
                                                    const int* __restrict__ klen, int rope_mode, float log_base,
-                                                   float gamma, int k_rot) {
+                                                   float gamma, int k_rot, const int* __restrict__ q_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ds = dh + 1;
     float* Qs = lds;               // [AQ][ds]
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
     const int nq = qlen ? qlen[b] : Lq;  // used for length-aware positions only
     const float sc = rsqrtf((float)dh);
 
-    stage_rows<T>(q + h * dh, ldq, (int64_t)b * Lq, q0, AQ, Lq, dh, ds, Qs, rope_mode, log_base, gamma, nq, sc);
+    const int64_t qrow0 = q_off ? (int64_t)q_off[b] : (int64_t)b * Lq;  // packed: the sequence owns nq rows from q_off[b]
+    const int qrows = q_off ? nq : Lq;
+    if (q0 >= qrows) return;  // uniform: nothing of this tile exists
+    stage_rows<T>(q + h * dh, ldq, qrow0, q0, AQ, qrows, dh, ds, Qs, rope_mode, log_base, gamma, nq, sc);
 
     float m_run = -1e30f, l_run = 0.f;
     float oacc[ADH_MAX / 8];
@@ -130,9 +133,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
         }
     }
     const int gq = q0 + qi;
-    if (gq < Lq) {
+    if (gq < qrows) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        T* orow = o + ((int64_t)b * Lq + gq) * ldo + h * dh + g;
+        T* orow = o + (qrow0 + gq) * ldo + h * dh + g;
 #pragma unroll
         for (int i = 0; i < ADH_MAX / 8; ++i)
             if (8 * i + g < dh) st_act(orow + 8 * i, oacc[i] * inv);
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                                                         int ldk, uint16_t* __restrict__ o, int ldo, int Lq, int Lk,
                                                         int lk_pad, const int* __restrict__ qlen,
                                                         const int* __restrict__ klen, int rope_mode, float log_base,
-                                                        float gamma, int k_rot) {
+                                                        float gamma, int k_rot, const int* __restrict__ q_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float inv_rev[DH / 2];  // rotation frequency of pair i in REVOLUTIONS per position unit (v_sin/v_cos input)
     constexpr int QS = DH * 2 + 16;  // bytes per Q / K row
@@ -181,6 +184,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nk = klen ? min(klen[b], Lk) : Lk;
     const int nq = qlen ? qlen[b] : Lq;
+    const int64_t qrow0 = q_off ? (int64_t)q_off[b] : (int64_t)b * Lq;  // packed: the sequence owns nq rows from q_off[b]
+    const int qrows = q_off ? nq : Lq;
+    if (q0 >= qrows) return;  // uniform: nothing of this tile exists
     constexpr int HD2 = DH / 2;
     const float qmul = rsqrtf((float)DH) * 1.44269504088896340736f;
 
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     for (int pass = 0; pass < 2; ++pass) {
         const uint16_t* src = pass == 0 ? q + h * DH : k + h * DH;
         const int ld = pass == 0 ? ldq : ldk;
-        const int64_t seq_base = pass == 0 ? (int64_t)b * Lq : (int64_t)b * Lk;
-        const int pos0 = pass == 0 ? q0 : 0, rows = pass == 0 ? 128 : lk_pad, limit = pass == 0 ? Lq : nk;
+        const int64_t seq_base = pass == 0 ? qrow0 : (int64_t)b * Lk;
+        const int pos0 = pass == 0 ? q0 : 0, rows = pass == 0 ? 128 : lk_pad, limit = pass == 0 ? qrows : nk;
         const int seq_len = pass == 0 ? nq : nk;
         const float mul = pass == 0 ? qmul : 1.f;
         const bool rot = rope_mode >= 0 && !(pass == 1 && k_rot);
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     }
     __syncthreads();
     const int qbase = wave * 32;
-    if (q0 + qbase >= Lq) return;  // this wave's 32 queries are all padding (no barrier follows)
+    if (q0 + qbase >= qrows) return;  // this wave's 32 queries are all padding (no barrier follows)
 
     const int lr = lane & 31, lh = lane >> 5;
     bf16x8_t bq[DH / 16];
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
         const int qrow = (i & 3) + 8 * (i >> 2) + 4 * lh;
         const float invq = __shfl(inv, qrow, 64);  // lane qrow (< 32) holds the sum of query qrow
         const int gq = q0 + qbase + qrow;
-        if (gq < Lq) {
-            uint16_t* orow = o + ((int64_t)b * Lq + gq) * ldo + h * DH + lr;
+        if (gq < qrows) {
+            uint16_t* orow = o + (qrow0 + gq) * ldo + h * DH + lr;
 #pragma unroll
             for (int nd = 0; nd < DH / 32; ++nd) orow[nd * 32] = (uint16_t)pack_bf16x2(oacc[nd][i] * invq, 0.f);
         }
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 template <int DH>
 static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
                              uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int lk_pad, size_t lds, const int* qlen,
-                             const int* klen, int rope_mode, float log_base, float gamma, int k_rot) {
+                             const int* klen, int rope_mode, float log_base, float gamma, int k_rot, const int* q_off) {
     static bool attr_set = false;
     if (!attr_set) {
         // 150 KiB dynamic (the launcher's own bound) + the kernel's static table stay inside the CU's 160 KiB
@@ -347,13 +353,14 @@ static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const ui
     }
     const dim3 grid((Lq + 127) / 128, H, B);
     STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
-                       rope_mode, log_base, gamma, k_rot);
+                       rope_mode, log_base, gamma, k_rot, q_off);
 }
 
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
-                      float rope_base, float rope_gamma, bool k_rotated) {
+                      float rope_base, float rope_gamma, bool k_rotated, const int* q_off) {
     if (B == 0 || Lq == 0) return;
+    if (q_off && !qlen) { fprintf(stderr, "stn: packed attention needs query lengths\n"); abort(); }
     if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
     if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
         !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
@@ -363,9 +370,9 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
             const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
             uint16_t* o16 = static_cast<uint16_t*>(o);
             const float lb = logf(rope_base);
-            if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated);
-            else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated);
-            else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated);
+            if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
+            else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
+            else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
             return;
         }
     }
@@ -382,11 +389,11 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (dtype == BF16)
         STN_KLAUNCH(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
                            static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), ldk, static_cast<uint16_t*>(o), ldo,
-                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated);
+                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off);
     else
         STN_KLAUNCH(attn_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(q), ldq,
                            static_cast<const float*>(k), static_cast<const float*>(v), ldk, static_cast<float*>(o), ldo, Lq, Lk,
-                           dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated);
+                           dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off);
 }
 
 // ---------------------------------------------------------------------------------------------

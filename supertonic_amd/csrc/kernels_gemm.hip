@@ -119,9 +119,12 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2]
             int b = 0, t = m;
             float keep = 1.f;
             if (need_bt) {
-                b = m / e.L;
-                t = m - b * e.L;
-                if (e.len && t >= e.len[b]) keep = 0.f;
+                if (e.row_b) { b = e.row_b[m]; t = 0; }
+                else {
+                    b = m / e.L;
+                    t = m - b * e.L;
+                    if (e.len && t >= e.len[b]) keep = 0.f;
+                }
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
@@ -464,8 +467,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
         const int m = m0 + row;
         if (m >= M) continue;
         float keep = 1.f;
-        const int b = (e.len || (MODE == EPI_RESID && e.rowvec)) ? m / e.L : 0;
-        if (e.len && m - b * e.L >= e.len[b]) keep = 0.f;
+        const int b = e.row_b ? e.row_b[m] : ((e.len || (MODE == EPI_RESID && e.rowvec)) ? m / e.L : 0);
+        if (!e.row_b && e.len && m - b * e.L >= e.len[b]) keep = 0.f;
         const float4 v0 = *reinterpret_cast<const float4*>(S + row * BN + c8 * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(S + row * BN + c8 * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -770,7 +773,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
             keep[it] = 1.f;
             off[it] = (size_t)m * e.ldo + n;
             bq[it] = 0;
-            if (ok[it] && (e.len || (MODE == EPI_RESID && e.rowvec))) {
+            if (ok[it] && e.row_b) {
+                bq[it] = e.row_b[m];  // packed rows: every row is valid, only the sequence index is needed
+            } else if (ok[it] && (e.len || (MODE == EPI_RESID && e.rowvec))) {
                 const int b = m / e.L;
                 bq[it] = b;
                 if (e.len && m - b * e.L >= e.len[b]) keep[it] = 0.f;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
                                                            const float* __restrict__ w_t, const float* __restrict__ bias,
                                                            int dil, int wps /*waves per sequence*/, const float* __restrict__ g,
                                                            const float* __restrict__ bt, float eps, OutT* __restrict__ y,
-                                                           const int* __restrict__ seqlen) {
+                                                           const int* __restrict__ seqlen, const int* __restrict__ row_off) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= (int64_t)nseq * wps) return;  // wave-uniform
@@ -229,18 +229,21 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
     const int Lv = seqlen ? seqlen[b] : L;  // valid frames of this sequence (<= L)
     constexpr int HALF = (K - 1) / 2, NWIN = R + K - 1;
     const int C4 = C >> 2;
+    // packed rows (row_off given): sequence b owns rows row_off[b] .. row_off[b] + seqlen[b]; else b*L .. b*L + L
+    const int64_t row0 = row_off ? (int64_t)row_off[b] : (int64_t)b * L;
     if (t0 >= Lv) {  // the whole comb lies in the padding: its rows are defined (zeros) but cost no loads or arithmetic
+        if (row_off) return;  // packed layout: there are no padding rows
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int t = t0 + r * dil;
             if (t >= L) break;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                if (lane + 64 * i < C4) store4(y + ((int64_t)b * L + t) * C + (lane + 64 * i) * 4, 0.f, 0.f, 0.f, 0.f);
+                if (lane + 64 * i < C4) store4(y + (row0 + t) * C + (lane + 64 * i) * 4, 0.f, 0.f, 0.f, 0.f);
         }
         return;
     }
-    const float4* x4 = reinterpret_cast<const float4*>(x) + (int64_t)b * L * C4;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + row0 * C4;
     const float4* w4 = reinterpret_cast<const float4*>(w_t);
     const float4* b4 = reinterpret_cast<const float4*>(bias);
     float4 h[R][2];
@@ -255,7 +258,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < NWIN; ++q) {
             const int tt = t0 + (q - HALF) * dil;
-            const int tc = tt < 0 ? 0 : (tt >= L ? L - 1 : tt);
+            const int hi_ = row_off ? Lv : L;  // clamp inside the rows this sequence owns
+            const int tc = tt < 0 ? 0 : (tt >= hi_ ? hi_ - 1 : tt);
             const float4 v = x4[(int64_t)tc * C4 + cc];
             const float keep = (tt >= 0 && tt < Lv) ? 1.f : 0.f;
             win[q] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
@@ -295,17 +299,18 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
             }
         const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
         if (t >= L) continue;  // wave-uniform (tail of the sequence)
-        if (t >= Lv) {         // padding of a shorter sequence: zeros
+        if (t >= Lv) {         // padding of a shorter sequence: zeros (rows that do not exist in the packed layout)
+            if (row_off) continue;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                if (lane + 64 * i < C4) store4(y + ((int64_t)b * L + t) * C + (lane + 64 * i) * 4, 0.f, 0.f, 0.f, 0.f);
+                if (lane + 64 * i < C4) store4(y + (row0 + t) * C + (lane + 64 * i) * 4, 0.f, 0.f, 0.f, 0.f);
             continue;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c4 = lane + 64 * i;
             if (c4 < C4)
-                store4(y + ((int64_t)b * L + t) * C + c4 * 4, (h[r][i].x - mean) * rstd * gg[i].x + bb[i].x,
+                store4(y + (row0 + t) * C + c4 * 4, (h[r][i].x - mean) * rstd * gg[i].x + bb[i].x,
                        (h[r][i].y - mean) * rstd * gg[i].y + bb[i].y, (h[r][i].z - mean) * rstd * gg[i].z + bb[i].z,
                        (h[r][i].w - mean) * rstd * gg[i].w + bb[i].w);
         }
@@ -314,25 +319,30 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
 
 template <typename OutT, int K, int R>
 static void launch_dwconv_ln_v3_kr(hipStream_t s, const float* x, int nseq, int L, int C, const float* w_t, const float* bias,
-                                   int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen) {
+                                   int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen,
+                                   const int* row_off = nullptr) {
     const int wps = ((L + R * dil - 1) / (R * dil)) * dil;
     const int64_t nw = (int64_t)nseq * wps;
     STN_KLAUNCH((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
-                       dil, wps, g, b, eps, y, seqlen);
+                       dil, wps, g, b, eps, y, seqlen, row_off);
 }
 
 template <typename OutT>
 static bool launch_dwconv_ln_v3(hipStream_t s, const float* x, int nseq, int L, int C, const float* w_t, const float* bias,
-                                int k, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen) {
+                                int k, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen,
+                                const int* row_off = nullptr) {
     if (C > 512 || (k != 5 && k != 7)) return false;
     // enough wavefronts to fill the chip (256 CUs x ~8): long combs only when there are many frames
     const int64_t M = (int64_t)nseq * L;
     if (M >= 32768) {
-        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
-        else launch_dwconv_ln_v3_kr<OutT, 7, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+        else launch_dwconv_ln_v3_kr<OutT, 7, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     } else if (M >= 4096) {
-        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
-        else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen);
+        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+        else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+    } else if (row_off) {  // the packed layout only exists in this kernel
+        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+        else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     } else {
         return false;  // few frames: one wave per 2 frames (v2) exposes more parallelism
     }
@@ -354,14 +364,17 @@ static void check_ln_shape(int C) {
     if (C % 4 || C > 4 * 64 * LN_NI) { fprintf(stderr, "stn: LayerNorm width %d unsupported (C %% 4 == 0, C <= 1024)\n", C); abort(); }
 }
 
+bool dwconv_ln_supports_packed(int C, int k) { return C <= 512 && C % 4 == 0 && (k == 5 || k == 7); }
+
 void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L, int C, const float* w_t,
                       const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y,
-                      const int* seqlen) {
+                      const int* seqlen, const int* row_off) {
     check_ln_shape(C);
     const int64_t M = (int64_t)B * L;
     if (M == 0) return;
-    if (out_dtype == BF16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen)
-                          : launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen))
+    if (row_off && (!seqlen || !dwconv_ln_supports_packed(C, k))) { fprintf(stderr, "stn: packed dwconv_ln needs lengths, C <= 512, k in {5,7}\n"); abort(); }
+    if (out_dtype == BF16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen, row_off)
+                          : launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen, row_off))
         return;
     if (out_dtype == BF16 ? launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen)
                           : launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen))
@@ -424,38 +437,47 @@ void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len
 }
 
 template <typename OutT>
-__global__ void ncl_to_rows_kernel(const float* __restrict__ in, int C, int L, int ldo, int64_t n, OutT* __restrict__ out) {
+__global__ void ncl_to_rows_kernel(const float* __restrict__ in, int C, int L, int ldo, int64_t n, OutT* __restrict__ out,
+                                   const int* __restrict__ len, const int* __restrict__ row_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][L][ldo]
     if (i >= n) return;
     const int c = (int)(i % ldo);
     const int64_t r = i / ldo;
     const int t = (int)(r % L);
     const int64_t b = r / L;
-    store1(out + i, c < C ? in[(b * C + c) * L + t] : 0.f);
+    const float v = c < C ? in[(b * C + c) * L + t] : 0.f;
+    if (row_off) {  // packed destination: only the frames the sequence owns exist
+        if (t < len[b]) store1(out + ((int64_t)row_off[b] + t) * ldo + c, v);
+    } else {
+        store1(out + i, v);
+    }
 }
-void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out) {
+void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out, const int* len,
+                        const int* row_off) {
     const int ldo = ld_out > 0 ? ld_out : C;
     const int64_t n = (int64_t)B * ldo * L;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) STN_KLAUNCH(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out));
-    else STN_KLAUNCH(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out));
+    if (out_dtype == BF16) STN_KLAUNCH(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out), len, row_off);
+    else STN_KLAUNCH(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out), len, row_off);
 }
 
 // 32 x 32 LDS tile transpose: reads of v are coalesced along d, writes of out along t
 __global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict__ prev, const float* __restrict__ v,
                                                         const float* __restrict__ dt, const int* __restrict__ len, int D, int L,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const int* __restrict__ row_off) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int n = len ? len[b] : L;
+    const int64_t vrow0 = row_off ? (int64_t)row_off[b] : (int64_t)b * L;
+    const int vrows = row_off ? n : L;  // rows of v this sequence owns
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int t = t0 + ty + 8 * k, d = d0 + tx;
-        tile[ty + 8 * k][tx] = (t < L && d < D) ? v[((int64_t)b * L + t) * D + d] : 0.f;
+        tile[ty + 8 * k][tx] = (t < vrows && d < D) ? v[(vrow0 + t) * D + d] : 0.f;
     }
     __syncthreads();
-    const int n = len ? len[b] : L;
     const float scale = dt[b];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -466,9 +488,32 @@ __global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict_
         }
     }
 }
-void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out) {
+void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out,
+                      const int* row_off) {
     if (B * D * L == 0) return;
-    STN_KLAUNCH(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out);
+    if (row_off && !len) { fprintf(stderr, "stn: packed euler_ncl needs lengths\n"); abort(); }
+    STN_KLAUNCH(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off);
+}
+
+// row_off[b] = sum of len[0..b) (row_off[B] = total), row_b[row_off[b] + t] = b: the packed-row bookkeeping, one block
+__global__ void row_map_kernel(const int* __restrict__ len, int B, int* __restrict__ row_off, int* __restrict__ row_b) {
+    __shared__ int off_s[1025];
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int b = 0; b < B; ++b) { off_s[b] = a; a += len[b]; }
+        off_s[B] = a;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= B; b += blockDim.x) row_off[b] = off_s[b];
+    for (int b = 0; b < B; ++b) {
+        const int o = off_s[b], n = off_s[b + 1] - o;
+        for (int t = threadIdx.x; t < n; t += blockDim.x) row_b[o + t] = b;
+    }
+}
+void launch_row_map(hipStream_t s, const int* len, int B, int* row_off, int* row_b) {
+    if (B <= 0) return;
+    if (B > 1024) { fprintf(stderr, "stn: packed layout supports at most 1024 sequences per batch\n"); abort(); }
+    STN_KLAUNCH(row_map_kernel, dim3(1), dim3(1024), 0, s, len, B, row_off, row_b);
 }
 
 template <typename OutT>

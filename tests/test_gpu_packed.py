@@ -1,0 +1,64 @@
+"""Packed ("ragged") rows in the vector estimator: an exact optimisation of the padded [b*L + t] layout — the masked stages are
+row-independent, so the latent after the Euler loop must agree between the two layouts (and with the oracle, which the other
+GPU tests check on the default, packed, layout)."""
+import numpy as np
+import pytest
+
+from supertonic_amd import binding
+from supertonic_amd.arch import default_arch, tiny_arch
+from gpu_util import make_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("arch_fn", [tiny_arch, default_arch])
+def test_packed_rows_equal_padded_rows(dtype, tol, arch_fn):
+    a = arch_fn()
+    eng = binding.Engine(0, dtype)
+    eng.load_synthetic(a, 7)
+    rng = np.random.default_rng(5)
+    for case in range(6):
+        B = [1, 2, 5, 9, 3, 16][case]
+        Lt = int(rng.integers(4, 50))
+        lens = rng.integers(1, Lt + 1, B)
+        lens[0] = Lt
+        ids, mask, sttl, sdp = make_inputs(a, B, Lt, lens, seed=case)
+        durs = rng.uniform(0.08, 2.5 if case else 0.3, B).astype(np.float32)
+        if case == 4:
+            durs[:] = durs[0]  # no padding at all: both layouts coincide
+        steps = [1, 2, 5, 3, 2, 4][case]
+        outs = {}
+        for packed in (False, True):
+            eng.set_packed_rows(packed)
+            w, d = eng.synthesize(ids, mask, sttl, sdp, steps, 1.05, duration_override=durs, noise_seed=7 + case)
+            outs[packed] = (w, d, eng.batch_fetch_latent())
+        np.testing.assert_array_equal(outs[True][1], outs[False][1])
+        mx, _ = rel_err(outs[True][2], outs[False][2])
+        assert mx < tol, (case, "latent", mx)
+        mx, _ = rel_err(outs[True][0], outs[False][0])
+        assert mx < 5 * tol, (case, "wav", mx)
+        # the padding of the latent is exactly zero in both
+        assert np.array_equal(outs[True][2] == 0, outs[False][2] == 0) or dtype == "bf16"
+    eng.set_packed_rows(True)
+
+
+def test_packed_graph_replay_and_length_changes():
+    """Replays stay exact; a change of the lengths (same shapes otherwise) re-captures instead of replaying a stale grid."""
+    a = tiny_arch()
+    eng = binding.Engine(0, "f32")
+    eng.load_synthetic(a, 7)
+    ids, mask, sttl, sdp = make_inputs(a, 4, 12, np.array([12, 5, 9, 2]), seed=2)
+    d1 = np.array([1.0, 0.4, 0.7, 0.2], np.float32)
+    d2 = np.array([1.0, 0.9, 0.3, 0.6], np.float32)  # same L (max), different sum of lengths
+    want = {}
+    for k, d in [(1, d1), (1, d1), (1, d1), (2, d2), (2, d2), (2, d2), (1, d1), (2, d2)]:
+        w, _ = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=d, noise_seed=3)
+        if k in want:
+            np.testing.assert_array_equal(w, want[k])
+        else:
+            want[k] = w
+    assert eng.graph_replays >= 2
+    eng.set_packed_rows(False)
+    w, _ = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=d2, noise_seed=3)
+    assert rel_err(w, want[2])[0] < 1e-4
