@@ -874,7 +874,7 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         // it still yields ~a full wave of workgroups (1 per CU); otherwise the 128x128 tile with 128-byte rows keeps more
         // CUs busy; tiny M (single utterances) gets 64x64 tiles so that N is spread over more CUs.
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-        if (N >= 256 && t256 >= 200) {
+        if (N >= 256 && t256 >= 160) {  // (a packed batch leaves ~180 of these tiles: still better than 700 small ones)
             if (t256 < 512) cfg = 11;                      // one round of tiles: 16 waves shorten the per-tile critical path
             else if (K <= 512 && t256 >= 1024) cfg = 17;   // short K, many tiles: 256x128, 8 waves, 2 WGs/CU (4 % over the 4-wave form)
             else cfg = 1;
