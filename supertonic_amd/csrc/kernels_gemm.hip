@@ -551,7 +551,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     constexpr int PA = BM_ / RPP / NW, PW = BN_ / RPP / NW, PER = PA + PW;  // DMA pieces per wave per stage
     constexpr int STAGE = (BM_ + BN_) * ROWB;
     static_assert(ROWB == 64 || ROWB == 128, "row bytes");
-    static_assert(BM_ % (WM * 32) == 0 && BN_ % (WN * 32) == 0 && (BM_ / RPP) % NW == 0 && (BN_ / RPP) % NW == 0, "tile/wave shape");
+    // GEN: the 1-KiB DMA pieces of a stage do not divide evenly among the waves (3/4-size tiles: 192 or 96 rows on 12 or 6
+    // waves).  Then wave w takes pieces w, w + NW, ... of the whole stage (A rows first, W rows after), and the slots past
+    // the last piece become zero-byte loads into a per-wave scratch KiB so that every wave's vmcnt arithmetic stays uniform.
+    constexpr bool GEN = (BM_ / RPP) % NW != 0 || (BN_ / RPP) % NW != 0;
+    constexpr int PT = (BM_ + BN_) / RPP;                 // pieces per stage
+    constexpr int PERG = (PT + NW - 1) / NW;              // slots per wave and stage in the GEN scheme
+    static_assert(BM_ % (WM * 32) == 0 && BN_ % (WN * 32) == 0 && BM_ % RPP == 0 && BN_ % RPP == 0, "tile/wave shape");
     static_assert(NSTAGE * STAGE >= WM * 32 * BN_ * 4, "epilogue slab must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NSTAGE * STAGE bytes, the only LDS object
     const unsigned char* A = static_cast<const unsigned char*>(Av);
@@ -568,16 +574,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W + (size_t)n0 * ldw * ESZ, n0 < N ? (size_t)(N - n0) * ldw * ESZ : 0);
     // swizzle of the 16-B slot inside a row: 64-B rows use (row>>2)&3, 128-B rows (row>>1)&7 (see the bank analysis above)
     auto swz = [](int row) { return ROWB == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
-    unsigned offA[PA], offW[PW];
+    constexpr int PER_ = GEN ? PERG : PER;
+    unsigned offA[GEN ? 1 : PA], offW[GEN ? 1 : PW];
+    unsigned offG[GEN ? PERG : 1];
+    int kindG[GEN ? PERG : 1];  // 0 = A piece, 1 = W piece, 2 = padding slot (wave-uniform)
+    __amdgpu_buffer_rsrc_t rsZ = rsA;
+    if constexpr (GEN) {
+        rsZ = make_rsrc(A, 0);  // zero-length range: every lane out of range, no memory traffic
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int row = (PA * wave + j) * RPP + lane / CPR;
-        offA[j] = (unsigned)(row * lda + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
-    }
+        for (int j = 0; j < PERG; ++j) {
+            const int p = wave + NW * j;  // wave-uniform
+            const int row = p * RPP + lane / CPR;
+            if (p < BM_ / RPP) {
+                kindG[j] = 0;
+                offG[j] = (unsigned)(row * lda + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
+            } else if (p < PT) {
+                const int rw = row - BM_;
+                kindG[j] = 1;
+                offG[j] = (unsigned)(rw * ldw + (((lane % CPR) ^ swz(rw)) * EPC)) * (unsigned)ESZ;
+            } else {
+                kindG[j] = 2;
+                offG[j] = 0u;
+            }
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < PW; ++j) {
-        const int row = (PW * wave + j) * RPP + lane / CPR;
-        offW[j] = (unsigned)(row * ldw + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
+        for (int j = 0; j < PA; ++j) {
+            const int row = (PA * wave + j) * RPP + lane / CPR;
+            offA[j] = (unsigned)(row * lda + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int row = (PW * wave + j) * RPP + lane / CPR;
+            offW[j] = (unsigned)(row * ldw + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
+        }
     }
     const int nk = K / KS;
 
@@ -585,10 +615,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     {                                                                                                               \
         unsigned char* st_ = smem + ((kt) % NSTAGE) * STAGE;                                                        \
         const int ko_ = (kt) * ROWB;                                                                                \
-        _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                              \
-            dma16(rsA, st_ + (PA * wave + j) * 1024, offA[j], ko_);                                                  \
-        _Pragma("unroll") for (int j = 0; j < PW; ++j)                                                              \
-            dma16(rsW, st_ + BM_ * ROWB + (PW * wave + j) * 1024, offW[j], ko_);                                     \
+        if constexpr (GEN) {                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < PERG; ++j) {                                                      \
+                if (kindG[j] == 0) dma16(rsA, st_ + (wave + NW * j) * 1024, offG[j], ko_);                          \
+                else if (kindG[j] == 1) dma16(rsW, st_ + (wave + NW * j) * 1024, offG[j], ko_);                     \
+                else dma16(rsZ, smem + NSTAGE * STAGE + wave * 1024, 0u, 0);                                        \
+            }                                                                                                       \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                          \
+                dma16(rsA, st_ + (PA * wave + j) * 1024, offA[j], ko_);                                              \
+            _Pragma("unroll") for (int j = 0; j < PW; ++j)                                                          \
+                dma16(rsW, st_ + BM_ * ROWB + (PW * wave + j) * 1024, offW[j], ko_);                                 \
+        }                                                                                                           \
     }
 
     f32x16 acc[TM][TN];
@@ -605,7 +643,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
 
     const int lr = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        wait_stage<PER, NSTAGE - 2>(nk - 1 - kt);
+        wait_stage<PER_, NSTAGE - 2>(nk - 1 - kt);
         __builtin_amdgcn_s_barrier();
         if (e.ts && kt == 0) t_first = __builtin_readcyclecounter();
         const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
@@ -843,7 +881,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
 
 template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ = 2>
 static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const Epilogue& e) {
-    constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * ESZ;
+    constexpr int RPP_ = 1024 / (KS * ESZ), NW_ = WM * WN;
+    constexpr bool GEN_ = (BM_ / RPP_) % NW_ != 0 || (BN_ / RPP_) % NW_ != 0;
+    constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * ESZ + (GEN_ ? (size_t)NW_ * 1024 : 0);  // + padding-slot scratch
     static bool attr_set = false;
     if (!attr_set) {
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>),
@@ -875,19 +915,21 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         // CUs busy; tiny M (single utterances) gets 64x64 tiles so that N is spread over more CUs.
         const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
         if (N >= 256 && t256 >= 160) {  // (a packed batch leaves ~180 of these tiles: still better than 700 small ones)
-            if (t256 < 512) cfg = 11;                      // one round of tiles: 16 waves shorten the per-tile critical path
+            const long t192 = (long)((M + 191) / 192) * ((N + 255) / 256);
+            if (t256 < 208 && t192 <= 256) cfg = 18;       // one thin round (packed batches): 192-row tiles refill the idle CUs (-7 %)
+            else if (t256 < 512) cfg = 11;                 // one round of tiles: 16 waves shorten the per-tile critical path
             else if (K <= 512 && t256 >= 1024) cfg = 17;   // short K, many tiles: 256x128, 8 waves, 2 WGs/CU (4 % over the 4-wave form)
             else cfg = 1;
         } else if (K % 64 == 0) cfg = M <= 64 ? 12 : 8;
         else return false;
     }
-    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14) && K % 64) return false;
+    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 19) && K % 64) return false;
     static int g_tr = -2;
     if (g_tr == -2) { const char* c = getenv("STN_GEMM_TR"); g_tr = c ? atoi(c) : 1; }
     Epilogue et = e;
     // the transposed-image epilogue stores 64-byte row segments (16 rows per instruction): a win where a CU runs one tile
     // (-4 % ve.pw1, -15 % te.pw1), a loss where a co-resident workgroup's K loop competes for the vector-memory path (vo.pw1)
-    et.tr_epilogue = g_tr == 2 || (g_tr == 1 && (cfg == 11 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14));
+    et.tr_epilogue = g_tr == 2 || (g_tr == 1 && (cfg == 11 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 18 || cfg == 19));
     const Epilogue& e_ = et;
     switch (cfg) {
         case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
@@ -907,6 +949,8 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         case 15: launch_tiled<MODE, 128, 128, 2, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 48 KiB: 3 WGs / CU
         case 16: launch_tiled<MODE, 128, 256, 2, 4, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB, 8 waves: 2 WGs / CU
         case 17: launch_tiled<MODE, 256, 128, 4, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB, 8 waves: 2 WGs / CU
+        case 18: launch_tiled<MODE, 192, 256, 3, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 12 waves: 3/4 of config 11, same work per wave
+        case 19: launch_tiled<MODE, 96, 128, 3, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;   // 6 waves: 3/4 of config 8, same work per wave
         default: return false;
     }
 }
