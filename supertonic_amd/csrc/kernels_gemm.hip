@@ -923,13 +923,13 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         } else if (K % 64 == 0) cfg = M <= 64 ? 12 : 8;
         else return false;
     }
-    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 19) && K % 64) return false;
+    if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14) && K % 64) return false;
     static int g_tr = -2;
     if (g_tr == -2) { const char* c = getenv("STN_GEMM_TR"); g_tr = c ? atoi(c) : 1; }
     Epilogue et = e;
     // the transposed-image epilogue stores 64-byte row segments (16 rows per instruction): a win where a CU runs one tile
     // (-4 % ve.pw1, -15 % te.pw1), a loss where a co-resident workgroup's K loop competes for the vector-memory path (vo.pw1)
-    et.tr_epilogue = g_tr == 2 || (g_tr == 1 && (cfg == 11 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 18 || cfg == 19));
+    et.tr_epilogue = g_tr == 2 || (g_tr == 1 && (cfg == 11 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 18));
     const Epilogue& e_ = et;
     switch (cfg) {
         case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
@@ -950,7 +950,6 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         case 16: launch_tiled<MODE, 128, 256, 2, 4, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB, 8 waves: 2 WGs / CU
         case 17: launch_tiled<MODE, 256, 128, 4, 2, 3, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 72 KiB, 8 waves: 2 WGs / CU
         case 18: launch_tiled<MODE, 192, 256, 3, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;  // 12 waves: 3/4 of config 11, same work per wave
-        case 19: launch_tiled<MODE, 96, 128, 3, 2, 4, 64>(s, A, lda, W, ldw, M, N, K, e_); return true;   // 6 waves: 3/4 of config 8, same work per wave
         default: return false;
     }
 }
