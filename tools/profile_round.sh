@@ -25,8 +25,8 @@ S=$(find "$OUT" -name 'trace_kernel_stats.csv' | head -1)
 cp "$S" "profiles/${TAG}_bench_kernel_stats.csv"
 grep '^{' "$OUT/bench.json" | tail -1 > "profiles/${TAG}_bench.json"
 # dominant families of config C3 (kernel template, grid = workgroups x threads)
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 256, 256, 4, 4, 4, 32, 2>' --grid 239616
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw2_resid --kernel-substr 'gemm_tiled_kernel<1, 128, 128, 2, 4, 4, 64, 2>' --grid 119808
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 256, 128, 2, 2, 3, 32, 2>' --grid 958464
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 7, 8>'
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 5, 4>'
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 192, 256, 3, 4, 4, 32, 2>' --grid 179712 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw2_resid --kernel-substr 'gemm_tiled_kernel<1, 128, 128, 2, 4, 4, 64, 2>' --grid 90624 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 256, 128, 4, 2, 3, 32, 2>' --grid 1916928 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 7, 8>' || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 5, 4>' --grid 163840 || echo "  (no rows matched for this family)"
