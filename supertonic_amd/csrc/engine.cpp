@@ -664,18 +664,28 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
 // zero latent, which the convolutions see as signal).  vlen != nullptr (length-aware): convolution taps beyond an
 // utterance's own length read as the zero padding of a batch-of-one run, so wav[b, :vlen[b]*hop] equals what
 // synthesizing utterance b alone gives; samples past that are written as zeros.
-void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen) {
+void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen, int vrows) {
     stage_ = "vo";
     const stn_arch& a = a_;
     const int C = a.vo_dim, T = L * a.chunk_compress_factor;
-    const int64_t M = (int64_t)B * T;
+    // length-aware mode on packed rows: only the frames the utterances own exist (bf16 path; needs the comb dwconv kernel)
+    const bool packed = vlen && vrows > 0 && dt_ == BF16 && B <= 1024 && dwconv_ln_supports_packed(C, a.vo_kernel);
+    const int64_t M = packed ? (int64_t)vrows : (int64_t)B * T;
     const Arena::Mark mk = ar_.mark();
+    Ragged rg;
+    if (packed) {
+        int* off = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)(B + 1)));
+        launch_row_map(s_, vlen, B, off, nullptr);
+        rg.off = off; rg.rows = vrows;
+    }
+    const Ragged* rgp = packed ? &rg : nullptr;
     float* x = f32_alloc(M * C);
     if (dt_ == BF16) {
         // input conv on the MFMA path: im2col (K = ld*k padded to 64) + GEMM; ~10x the direct fp32 VALU kernel
         const int kp = (a.latent_dim * a.vo_in_kernel + 63) / 64 * 64;
         void* cols = act_alloc(M * kp);
-        launch_vocoder_im2col(s_, dt_, latent, B, L, a.latent_dim, a.chunk_compress_factor, a.vo_in_kernel, kp, cols, vlen);
+        launch_vocoder_im2col(s_, dt_, latent, B, L, a.latent_dim, a.chunk_compress_factor, a.vo_in_kernel, kp, cols, vlen,
+                              packed ? rg.off : nullptr);
         Linear lin;
         lin.w = tensor("vo.in_gemm.w"); lin.b = vecf("vo.in.b"); lin.N = C; lin.K = kp;
         Epilogue ei; ei.mode = EPI_STORE; ei.out_dtype = F32; ei.out = x; ei.ldo = C;
@@ -687,13 +697,21 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
         if (prof_on_) prof_end();
     }
     for (int i = 0; i < a.vo_blocks; ++i)
-        convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i], nullptr, vlen);
+        convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i],
+                 packed ? vlen : nullptr, packed ? nullptr : vlen, nullptr, 0, rgp);
     void* xn = act_alloc(M * C);
     const LNorm ln = lnorm("vo.out_ln");
     launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
     // head: transposed conv with kernel = stride = base_chunk_size == per-frame linear; rows of the GEMM output ARE the wave
-    Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wav; e.ldo = a.base_chunk_size; e.len = vlen; e.L = T;
-    gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
+    if (packed) {
+        float* wp = f32_alloc(M * a.base_chunk_size);
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wp; e.ldo = a.base_chunk_size;
+        gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
+        launch_unpack_rows(s_, wp, vlen, rg.off, B, T, a.base_chunk_size, wav);
+    } else {
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wav; e.ldo = a.base_chunk_size; e.len = vlen; e.L = T;
+        gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
+    }
     ar_.release(mk);
 }
 
@@ -1006,7 +1024,9 @@ void Engine::enqueue_after_duration(int total_step) {
         launch_scale_len(s_, b.llen, B, a.chunk_compress_factor, v);
         vlen = v;
     }
-    vocoder_dev(B, L, b.xt[cur], b.wav, vlen);
+    int vrows = 0;
+    if (vo_ragged_ && packed_ve_) for (int v : b.h_llen) vrows += v * a.chunk_compress_factor;
+    vocoder_dev(B, L, b.xt[cur], b.wav, vlen, vrows);
     STN_HIP(hipGetLastError());  // a kernel launch that was rejected (bad configuration) must not pass silently
 }
 

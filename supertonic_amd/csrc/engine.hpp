@@ -99,7 +99,8 @@ class Engine {
                      const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr,
                      const Ragged* rg = nullptr);
     // vlen (optional, device [B]): valid vocoder frames per utterance — the length-aware mode (see set_vocoder_mode)
-    void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr);
+    // vrows > 0 (with vlen): run the vocoder on packed rows — vrows = sum of vlen — and unpack into the padded wav at the end
+    void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr, int vrows = 0);
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
     void duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur);

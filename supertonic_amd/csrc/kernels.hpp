@@ -80,7 +80,7 @@ void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L
 // Packed ("ragged") rows: sequence b owns rows row_off[b] .. row_off[b] + len[b] of x / y and nothing else — no padding rows
 // exist.  row_off has B+1 entries (launch_row_map); supported where dwconv_ln_supports_packed(C, k).
 bool dwconv_ln_supports_packed(int C, int k);
-void launch_row_map(hipStream_t s, const int* len, int B, int* row_off /*[B+1]*/, int* row_b /*[sum len]*/);
+void launch_row_map(hipStream_t s, const int* len, int B, int* row_off /*[B+1]*/, int* row_b /*[sum len] or null*/);
 // plain LayerNorm over C: x fp32 -> y act
 void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
                       float eps, void* y);
@@ -124,7 +124,10 @@ void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld,
 // vocoder front as im2col for the MFMA path: cols[r][ci*k + j] = frame(t + j - k/2)[ci] (0 outside the sequence / beyond ld*k),
 // frame (b, t = l*ccf + q) channel c <- latent[b][q*ld + c][l]; row stride kp (>= ld*k, zero padded), act dtype
 void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols,
-                           const int* seqlen = nullptr /* valid vocoder frames per sequence */);
+                           const int* seqlen = nullptr /* valid vocoder frames per sequence */,
+                           const int* row_off = nullptr /* packed destination rows (needs seqlen) */);
+// packed rows [sum len][W] -> padded [B][T][W], zeros past each sequence's length
+void launch_unpack_rows(hipStream_t s, const float* src, const int* len, const int* row_off, int B, int T, int W, float* dst);
 // masked mean over valid rows: pooled[b][c] = sum_{t<len[b]} x[b*L+t][c] / max(len[b],1)   (x act dtype, out fp32)
 void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled);
 // y = softplus(x) elementwise (n small)

@@ -505,10 +505,31 @@ __global__ void row_map_kernel(const int* __restrict__ len, int B, int* __restri
     }
     __syncthreads();
     for (int b = threadIdx.x; b <= B; b += blockDim.x) row_off[b] = off_s[b];
+    if (!row_b) return;
     for (int b = 0; b < B; ++b) {
         const int o = off_s[b], n = off_s[b + 1] - o;
         for (int t = threadIdx.x; t < n; t += blockDim.x) row_b[o + t] = b;
     }
+}
+
+// packed rows [sum len][W] -> padded [B][T][W] with zeros past each sequence's length (W % 4 == 0)
+__global__ void unpack_rows_kernel(const float* __restrict__ src, const int* __restrict__ len, const int* __restrict__ row_off, int T,
+                                   int W4, int64_t n4, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][T][W/4]
+    if (i >= n4) return;
+    const int c = (int)(i % W4);
+    const int64_t r = i / W4;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < len[b]) v = reinterpret_cast<const float4*>(src)[((int64_t)row_off[b] + t) * W4 + c];
+    reinterpret_cast<float4*>(dst)[i] = v;
+}
+void launch_unpack_rows(hipStream_t s, const float* src, const int* len, const int* row_off, int B, int T, int W, float* dst) {
+    const int64_t n4 = (int64_t)B * T * (W / 4);
+    if (n4 == 0) return;
+    if (W % 4) { fprintf(stderr, "stn: unpack_rows needs W %% 4 == 0\n"); abort(); }
+    STN_KLAUNCH(unpack_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, len, row_off, T, W / 4, n4, dst);
 }
 void launch_row_map(hipStream_t s, const int* len, int B, int* row_off, int* row_b) {
     if (B <= 0) return;
@@ -614,7 +635,8 @@ void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld,
 
 template <typename OutT>
 __global__ void vocoder_im2col_kernel(const float* __restrict__ latent, int L, int ld, int ccf, int k, int kp, int64_t n,
-                                      OutT* __restrict__ cols, const int* __restrict__ seqlen) {
+                                      OutT* __restrict__ cols, const int* __restrict__ seqlen,
+                                      const int* __restrict__ row_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B*T][kp]
     if (i >= n) return;
     const int col = (int)(i % kp);
@@ -622,6 +644,7 @@ __global__ void vocoder_im2col_kernel(const float* __restrict__ latent, int L, i
     const int T = L * ccf, D = ld * ccf;
     const int t = (int)(r % T);
     const int64_t b = r / T;
+    if (row_off && t >= seqlen[b]) return;  // packed destination: frames past the sequence do not exist
     float v = 0.f;
     if (col < ld * k) {
         const int ci = col / k, j = col - ci * k;
@@ -631,15 +654,15 @@ __global__ void vocoder_im2col_kernel(const float* __restrict__ latent, int L, i
             v = latent[(b * D + q * ld + ci) * L + l];
         }
     }
-    store1(cols + i, v);
+    store1(row_off ? cols + ((int64_t)row_off[b] + t) * kp + col : cols + i, v);
 }
 void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols,
-                           const int* seqlen) {
+                           const int* seqlen, const int* row_off) {
     const int64_t n = (int64_t)B * L * ccf * kp;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) STN_KLAUNCH(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen);
-    else STN_KLAUNCH(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols), seqlen);
+    if (out_dtype == BF16) STN_KLAUNCH(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen, row_off);
+    else STN_KLAUNCH(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols), seqlen, row_off);
 }
 
 template <typename InT>

@@ -62,3 +62,31 @@ def test_packed_graph_replay_and_length_changes():
     eng.set_packed_rows(False)
     w, _ = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=d2, noise_seed=3)
     assert rel_err(w, want[2])[0] < 1e-4
+
+
+def test_length_aware_vocoder_packed_equals_padded():
+    """In the length-aware mode the vocoder runs on packed rows too (bf16): same waveform as on padded rows, exact zeros past
+    every utterance's own length."""
+    a = default_arch()
+    eng = binding.Engine(0, "bf16")
+    eng.load_synthetic(a, 7)
+    rng = np.random.default_rng(11)
+    B, Lt = 7, 40
+    lens = rng.integers(3, Lt + 1, B)
+    lens[2] = Lt
+    ids, mask, sttl, sdp = make_inputs(a, B, Lt, lens, seed=9)
+    durs = rng.uniform(0.1, 2.0, B).astype(np.float32)
+    eng.set_vocoder_mode(True)
+    outs = {}
+    for packed in (False, True):
+        eng.set_packed_rows(packed)
+        for _ in range(3):  # eager, capture, replay
+            w, d = eng.synthesize(ids, mask, sttl, sdp, 3, 1.0, duration_override=durs, noise_seed=21)
+            if packed in outs:
+                np.testing.assert_array_equal(w, outs[packed])
+            outs[packed] = w
+    mx, rms = rel_err(outs[True], outs[False])
+    assert mx < 5e-2 and rms < 5e-3, (mx, rms)
+    assert np.array_equal(outs[True] == 0, outs[False] == 0)
+    eng.set_vocoder_mode(False)
+    eng.set_packed_rows(True)
