@@ -90,3 +90,26 @@ def test_length_aware_vocoder_packed_equals_padded():
     assert np.array_equal(outs[True] == 0, outs[False] == 0)
     eng.set_vocoder_mode(False)
     eng.set_packed_rows(True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_zero_length_utterance_in_a_packed_batch(dtype):
+    """A duration of zero gives an utterance no latent frame at all: it owns no row in the packed layout; its waveform is the
+    vocoder's response to an all-zero latent, as on padded rows."""
+    a = tiny_arch()
+    eng = binding.Engine(0, dtype)
+    eng.load_synthetic(a, 7)
+    ids, mask, sttl, sdp = make_inputs(a, 4, 9, np.array([9, 3, 6, 1]), seed=4)
+    durs = np.array([0.6, 1e-5, 0.25, 1e-5], np.float32)  # int(1e-5 * 44100) = 0 samples -> 0 latent frames (cpp/helper.cpp:764-768)
+    outs = {}
+    for packed in (False, True):
+        eng.set_packed_rows(packed)
+        w, d = eng.synthesize(ids, mask, sttl, sdp, 3, 1.0, duration_override=durs, noise_seed=2)
+        lat = eng.batch_fetch_latent()
+        assert np.all(np.isfinite(w)) and np.all(lat[1] == 0) and np.all(lat[3] == 0)
+        outs[packed] = (w, lat)
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    assert rel_err(outs[True][1], outs[False][1])[0] < tol
+    assert rel_err(outs[True][0], outs[False][0])[0] < 5 * tol
+    np.testing.assert_array_equal(outs[True][0][1], outs[True][0][3])  # two silent utterances: identical output
+    eng.set_packed_rows(True)
