@@ -27,6 +27,13 @@ inline thread_local LaunchEvents g_launch_ev;
         }                                                                                                               \
     } while (0)
 
+// hipFuncSetAttribute is per device: one flag per (kernel instantiation, device) so that several handles on different GPUs in
+// one process each opt their device in (flags are only ever set to true, so a race merely repeats the call)
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool need() { int d = 0; (void)hipGetDevice(&d); d &= 63; if (done[d]) return false; done[d] = true; return true; }
+};
+
 // launch-side HIP calls that must not fail silently (a failed attribute call leaves a sticky error that surfaces in
 // whatever library checks hipGetLastError next)
 inline void stn_check_hip(hipError_t e, const char* what) {

@@ -345,11 +345,10 @@ template <int DH>
 static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
                              uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int lk_pad, size_t lds, const int* qlen,
                              const int* klen, int rope_mode, float log_base, float gamma, int k_rot, const int* q_off) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         // 150 KiB dynamic (the launcher's own bound) + the kernel's static table stay inside the CU's 160 KiB
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(attn_mfma)");
-        attr_set = true;
     }
     const dim3 grid((Lq + 127) / 128, H, B);
     STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
@@ -380,11 +379,10 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     const size_t lds = sizeof(float) * ((size_t)(AQ + 2 * AK) * ds + (size_t)AQ * (AK + 1));
     const dim3 grid((Lq + AQ - 1) / AQ, H, B);
     const float log_base = logf(rope_base);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f32)");
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn bf16)");
-        attr_set = true;
     }
     if (dtype == BF16)
         STN_KLAUNCH(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,

@@ -884,11 +884,10 @@ static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, i
     constexpr int RPP_ = 1024 / (KS * ESZ), NW_ = WM * WN;
     constexpr bool GEN_ = (BM_ / RPP_) % NW_ != 0 || (BN_ / RPP_) % NW_ != 0;
     constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * ESZ + (GEN_ ? (size_t)NW_ * 1024 : 0);  // + padding-slot scratch
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(gemm_tiled)");
-        attr_set = true;
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
     STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A, lda,
