@@ -106,6 +106,8 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * latent frames each utterance owns (sum of lengths rows), 0 = padded [b*L + t] rows with the padding masked to zero after
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
+/* rows the vector estimator worked on in the last stn_batch_run: sum of the latent lengths (packed) or B*L (padded) */
+int64_t stn_batch_ve_rows(const stn_handle* h);
 int64_t stn_graph_replays(const stn_handle* h);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
 int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);

@@ -936,7 +936,8 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     GraphKey key;
     key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.gen = b.gen;
     key.rows = 0;
-    if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
+    if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;
+    last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
     if (graphable && graph_exec_ && key == graph_key_) {

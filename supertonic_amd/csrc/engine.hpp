@@ -143,6 +143,7 @@ class Engine {
     void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
+    int64_t last_ve_rows() const { return last_ve_rows_; }  // rows the estimator worked on in the last batch_run
     bool packed_rows_ok(int B) const { return packed_ve_ && B <= 1024 && a_.ve_dilated > 0 && dwconv_ln_supports_packed(a_.ve_dim, a_.ve_kernel); }
     long graph_replays() const { return graph_replays_; }
     const Batch& batch() const { return bt_; }
@@ -228,6 +229,7 @@ class Engine {
     bool graph_on_ = true;
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
+    int64_t last_ve_rows_ = 0;
     GraphKey graph_key_, warm_key_;
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t graph_ = nullptr;

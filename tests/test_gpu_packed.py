@@ -4,7 +4,7 @@ GPU tests check on the default, packed, layout)."""
 import numpy as np
 import pytest
 
-from supertonic_amd import binding
+from supertonic_amd import binding, host
 from supertonic_amd.arch import default_arch, tiny_arch
 from gpu_util import make_inputs, rel_err
 
@@ -33,6 +33,10 @@ def test_packed_rows_equal_padded_rows(dtype, tol, arch_fn):
             eng.set_packed_rows(packed)
             w, d = eng.synthesize(ids, mask, sttl, sdp, steps, 1.05, duration_override=durs, noise_seed=7 + case)
             outs[packed] = (w, d, eng.batch_fetch_latent())
+            _, L, _ = eng.batch_dims()
+            lens_lat = host.latent_geometry(d, a.sample_rate, a.base_chunk_size, a.chunk_compress_factor, a.latent_dim)[2]
+            supported = a.ve_kernel in (5, 7) and a.ve_dim <= 512  # the comb dwconv kernel carries the packed layout
+            assert eng.ve_rows == (int(np.sum(lens_lat)) if packed and supported else B * L), (case, packed, eng.ve_rows)
         np.testing.assert_array_equal(outs[True][1], outs[False][1])
         mx, _ = rel_err(outs[True][2], outs[False][2])
         assert mx < tol, (case, "latent", mx)
