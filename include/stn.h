@@ -108,6 +108,9 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
 int stn_set_row_layout(stn_handle* h, int packed);
 /* rows the vector estimator worked on in the last stn_batch_run: sum of the latent lengths (packed) or B*L (padded) */
 int64_t stn_batch_ve_rows(const stn_handle* h);
+/* frames the vocoder computed in the last stn_batch_run: B*L*ccf, or fewer when the position-independent part of the padding
+ * was filled from the model's cached zero-latent response (bit-identical result; bf16 engines, packed row layout) */
+int64_t stn_batch_vo_rows(const stn_handle* h);
 int64_t stn_graph_replays(const stn_handle* h);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);
 int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float* duration);

@@ -64,6 +64,8 @@ def load():
     L.stn_set_row_layout.argtypes = [vp, ci]
     L.stn_batch_ve_rows.argtypes = [vp]
     L.stn_batch_ve_rows.restype = ctypes.c_int64
+    L.stn_batch_vo_rows.argtypes = [vp]
+    L.stn_batch_vo_rows.restype = ctypes.c_int64
     L.stn_graph_replays.restype = ctypes.c_int64
     L.stn_graph_replays.argtypes = [vp]
     L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
@@ -217,6 +219,10 @@ class Engine:
     def set_packed_rows(self, on=True):
         """Vector-estimator row layout in batch_run: packed (default, no work on padding) or padded [b*L + t]."""
         self._ck(self._lib.stn_set_row_layout(self._h, int(bool(on))))
+
+    @property
+    def vo_rows(self):
+        return self._lib.stn_batch_vo_rows(self._h)
 
     @property
     def ve_rows(self):

@@ -244,6 +244,7 @@ int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_see
                  h->eng->batch_run(total_step, speed, noise_seed); })
 }
 int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_mode(on != 0); }) }
+int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows() : 0; }
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
 int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }

@@ -120,6 +120,8 @@ Engine::~Engine() {
     free_weights();
     for (void* p : batch_owned_) (void)hipFree(p);
     for (void* p : batch_retired_) (void)hipFree(p);
+    if (vo_quiet_) (void)hipFree(vo_quiet_);
+    if (vo_edge_) (void)hipFree(vo_edge_);
     for (auto& sp : spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
@@ -330,7 +332,10 @@ void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<s
     for (int i = 0; i < a.vo_blocks; ++i) decl_convnext(S("vo.blk%d", i), a.vo_dim, a.vo_hidden, a.vo_kernel);
     decl_ln("vo.out_ln", a.vo_dim);
     decl_linear("vo.head", a.base_chunk_size, a.vo_dim, a.head_gain, false);
-    if (!names_only) loaded_ = true;
+    if (!names_only) {
+        loaded_ = true;
+        prepare_vocoder_constants();
+    }
 }
 
 // =================================================================================================
@@ -660,16 +665,65 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     ar_.release(mk);
 }
 
+int Engine::vocoder_receptive_field() const {
+    int rf = (a_.vo_in_kernel - 1) / 2;
+    for (int i = 0; i < a_.vo_blocks; ++i) rf += (a_.vo_kernel - 1) / 2 * a_.vo_dilations[i];
+    return rf;
+}
+
+// The vocoder's response to zero latent is position-independent away from data and edges.  One run on a short all-zero
+// latent yields the two pieces every padded tail is made of: the frame whose whole receptive field is zero latent ("quiet"),
+// and the last rf frames before the end of the tensor ("edge").  bf16 engines only (the packed vocoder path).
+void Engine::prepare_vocoder_constants() {
+    if (vo_quiet_) { (void)hipFree(vo_quiet_); vo_quiet_ = nullptr; }
+    if (vo_edge_) { (void)hipFree(vo_edge_); vo_edge_ = nullptr; }
+    vo_rf_ = 0;
+    const stn_arch& a = a_;
+    if (dt_ != BF16 || !dwconv_ln_supports_packed(a.vo_dim, a.vo_kernel) || a.base_chunk_size % 4) return;
+    const int rf = vocoder_receptive_field(), ccf = a.chunk_compress_factor, W = a.base_chunk_size;
+    const int Lz = (4 * rf + ccf) / ccf + 1, Tz = Lz * ccf, D = a.latent_dim * ccf;
+    ar_.reset();
+    float* lat = f32_alloc((int64_t)D * Lz);
+    float* wz = f32_alloc((int64_t)Tz * W);
+    STN_HIP(hipMemsetAsync(lat, 0, sizeof(float) * (size_t)D * Lz, s_));
+    vocoder_dev(1, Lz, lat, wz);
+    STN_HIP(hipMalloc(reinterpret_cast<void**>(&vo_quiet_), sizeof(float) * (size_t)W));
+    STN_HIP(hipMalloc(reinterpret_cast<void**>(&vo_edge_), sizeof(float) * (size_t)rf * W));
+    STN_HIP(hipMemcpyAsync(vo_quiet_, wz + (size_t)2 * rf * W, sizeof(float) * (size_t)W, hipMemcpyDeviceToDevice, s_));
+    STN_HIP(hipMemcpyAsync(vo_edge_, wz + (size_t)(Tz - rf) * W, sizeof(float) * (size_t)rf * W, hipMemcpyDeviceToDevice, s_));
+    sync();
+    vo_rf_ = rf;
+}
+
+// host mirror of trim_len_kernel: the packed row count (0 when trimming does not apply to this batch)
+int Engine::trimmed_rows(int B, int L, std::vector<int>* n_host) const {
+    if (!packed_ve_ || vo_ragged_ || !vo_quiet_ || vo_rf_ <= 0 || B > 1024) return 0;
+    const int ccf = a_.chunk_compress_factor, T = L * ccf, rf = vo_rf_;
+    long tot = 0;
+    bool any = false;
+    for (int i = 0; i < B; ++i) {
+        const int l6 = bt_.h_llen[i] * ccf;
+        const bool trim = l6 + 2 * rf <= T - rf;
+        any = any || trim;
+        const int n = trim ? l6 + 2 * rf : T;
+        if (n_host) n_host->push_back(n);
+        tot += n;
+    }
+    // the unpack pass costs about as much as 3 % of the frames: trim only when it removes clearly more than that
+    return (any && tot * 10 <= (long)B * T * 9) ? (int)tot : 0;
+}
+
 // vlen == nullptr: every utterance is decoded over all T frames (the reference's batched vocoder Run: the padding is
 // zero latent, which the convolutions see as signal).  vlen != nullptr (length-aware): convolution taps beyond an
 // utterance's own length read as the zero padding of a batch-of-one run, so wav[b, :vlen[b]*hop] equals what
 // synthesizing utterance b alone gives; samples past that are written as zeros.
-void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen, int vrows) {
+void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen, int vrows, const int* valid) {
     stage_ = "vo";
     const stn_arch& a = a_;
     const int C = a.vo_dim, T = L * a.chunk_compress_factor;
     // length-aware mode on packed rows: only the frames the utterances own exist (bf16 path; needs the comb dwconv kernel)
     const bool packed = vlen && vrows > 0 && dt_ == BF16 && B <= 1024 && dwconv_ln_supports_packed(C, a.vo_kernel);
+    if (valid && !packed) throw std::runtime_error("trimmed vocoder needs the packed bf16 path");
     const int64_t M = packed ? (int64_t)vrows : (int64_t)B * T;
     const Arena::Mark mk = ar_.mark();
     Ragged rg;
@@ -707,7 +761,8 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
         float* wp = f32_alloc(M * a.base_chunk_size);
         Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wp; e.ldo = a.base_chunk_size;
         gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
-        launch_unpack_rows(s_, wp, vlen, rg.off, B, T, a.base_chunk_size, wav);
+        if (valid) launch_unpack_rows_quiet(s_, wp, valid, rg.off, B, T, a.base_chunk_size, vo_rf_, vo_quiet_, vo_edge_, wav);
+        else launch_unpack_rows(s_, wp, vlen, rg.off, B, T, a.base_chunk_size, wav);
     } else {
         Epilogue e; e.mode = EPI_STORE; e.out_dtype = F32; e.out = wav; e.ldo = a.base_chunk_size; e.len = vlen; e.L = T;
         gemm("gemm_head", dt_, xn, C, linear("vo.head"), (int)M, e);
@@ -937,7 +992,11 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.gen = b.gen;
     key.rows = 0;
     if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;
-    last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
+    last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L;
+    key.vrows = trimmed_rows(B, L, nullptr);
+    last_vo_rows_ = (int64_t)B * L * a.chunk_compress_factor;
+    if (vo_ragged_ && packed_ve_ && dt_ == BF16) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
+    else if (key.vrows) last_vo_rows_ = key.vrows; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
     if (graphable && graph_exec_ && key == graph_key_) {
@@ -1026,8 +1085,17 @@ void Engine::enqueue_after_duration(int total_step) {
         vlen = v;
     }
     int vrows = 0;
-    if (vo_ragged_ && packed_ve_) for (int v : b.h_llen) vrows += v * a.chunk_compress_factor;
-    vocoder_dev(B, L, b.xt[cur], b.wav, vlen, vrows);
+    const int* valid = nullptr;
+    if (vo_ragged_ && packed_ve_) {
+        for (int v : b.h_llen) vrows += v * a.chunk_compress_factor;
+    } else if (const int tr = trimmed_rows(B, L, nullptr)) {
+        // reference (dense) semantics at the cost of the frames that are not position-independent
+        int* n_dev = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+        int* v_dev = static_cast<int*>(ar_.alloc(sizeof(int) * B));
+        launch_trim_len(s_, b.llen, B, a.chunk_compress_factor, L * a.chunk_compress_factor, vo_rf_, n_dev, v_dev);
+        vlen = n_dev; valid = v_dev; vrows = tr;
+    }
+    vocoder_dev(B, L, b.xt[cur], b.wav, vlen, vrows, valid);
     STN_HIP(hipGetLastError());  // a kernel launch that was rejected (bad configuration) must not pass silently
 }
 

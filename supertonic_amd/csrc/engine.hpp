@@ -100,7 +100,12 @@ class Engine {
                      const Ragged* rg = nullptr);
     // vlen (optional, device [B]): valid vocoder frames per utterance — the length-aware mode (see set_vocoder_mode)
     // vrows > 0 (with vlen): run the vocoder on packed rows — vrows = sum of vlen — and unpack into the padded wav at the end
-    void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr, int vrows = 0);
+    // valid (with vlen, vrows): the exact trimmed DENSE mode — rows are computed on vlen[b] frames, exact below valid[b], and
+    // the rest of each row is the cached zero-latent response (quiet chunk + edge tail)
+    void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr, int vrows = 0,
+                     const int* valid = nullptr);
+    int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
+    void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
     void duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur);
@@ -143,7 +148,8 @@ class Engine {
     void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
-    int64_t last_ve_rows() const { return last_ve_rows_; }  // rows the estimator worked on in the last batch_run
+    int64_t last_ve_rows() const { return last_ve_rows_; }
+    int64_t last_vo_rows() const { return last_vo_rows_; }  // frames the vocoder computed in the last batch_run  // rows the estimator worked on in the last batch_run
     bool packed_rows_ok(int B) const { return packed_ve_ && B <= 1024 && a_.ve_dilated > 0 && dwconv_ln_supports_packed(a_.ve_dim, a_.ve_kernel); }
     long graph_replays() const { return graph_replays_; }
     const Batch& batch() const { return bt_; }
@@ -223,13 +229,17 @@ class Engine {
     std::vector<float> reported_dur_;
     void enqueue_after_duration(int total_step);
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int rows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
-        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && rows == o.rows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int rows = 0, vrows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && rows == o.rows && vrows == o.vrows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
     };
     bool graph_on_ = true;
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
-    int64_t last_ve_rows_ = 0;
+    int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
+    float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), bf16 engines
+    float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }
+    int vo_rf_ = 0;
+    int trimmed_rows(int B, int L, std::vector<int>* n_host) const;  // sum of the trimmed extents (0: trimming not applicable)
     GraphKey graph_key_, warm_key_;
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t graph_ = nullptr;

@@ -135,6 +135,10 @@ void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, in
                            const int* row_off = nullptr /* packed destination rows (needs seqlen) */);
 // packed rows [sum len][W] -> padded [B][T][W], zeros past each sequence's length
 void launch_unpack_rows(hipStream_t s, const float* src, const int* len, const int* row_off, int B, int T, int W, float* dst);
+// exact trimmed dense vocoder (see kernels_misc.hip): extents per utterance, and the unpack that fills the position-independent tail
+void launch_trim_len(hipStream_t s, const int* len, int B, int ccf, int T, int rf, int* n_out, int* valid_out);
+void launch_unpack_rows_quiet(hipStream_t s, const float* src, const int* valid, const int* row_off, int B, int T, int W, int rf,
+                              const float* quiet, const float* edge, float* dst);
 // masked mean over valid rows: pooled[b][c] = sum_{t<len[b]} x[b*L+t][c] / max(len[b],1)   (x act dtype, out fp32)
 void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled);
 // y = softplus(x) elementwise (n small)

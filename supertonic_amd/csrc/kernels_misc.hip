@@ -777,6 +777,48 @@ void launch_scale_len(hipStream_t s, const int* len, int B, int factor, int* out
     STN_KLAUNCH(scale_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, factor, out);
 }
 
+// Extents of the exact "trimmed" dense vocoder: an utterance whose zero-latent padding is longer than twice the receptive
+// field rf is computed on len*ccf + 2*rf frames (zero beyond), which is exact on its first len*ccf + rf output frames; the rest
+// of its row is position-independent (quiet chunk + edge tail, see Engine::prepare_vocoder_constants).
+__global__ void trim_len_kernel(const int* __restrict__ len, int B, int ccf, int T, int rf, int* __restrict__ n_out,
+                                int* __restrict__ valid_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int l6 = len[i] * ccf;
+    const bool trim = l6 + 2 * rf <= T - rf;  // a quiet region and the full edge tail exist
+    n_out[i] = trim ? l6 + 2 * rf : T;
+    valid_out[i] = trim ? l6 + rf : T;
+}
+void launch_trim_len(hipStream_t s, const int* len, int B, int ccf, int T, int rf, int* n_out, int* valid_out) {
+    if (B == 0) return;
+    STN_KLAUNCH(trim_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, ccf, T, rf, n_out, valid_out);
+}
+
+// packed rows -> padded [B][T][W]: computed frames below valid[b], then the quiet chunk, then the edge tail of rf frames
+__global__ void unpack_rows_quiet_kernel(const float* __restrict__ src, const int* __restrict__ valid, const int* __restrict__ row_off,
+                                         int T, int W4, int rf, const float* __restrict__ quiet, const float* __restrict__ edge,
+                                         int64_t n4, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][T][W/4]
+    if (i >= n4) return;
+    const int c = (int)(i % W4);
+    const int64_t r = i / W4;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    float4 v;
+    if (t < valid[b]) v = reinterpret_cast<const float4*>(src)[((int64_t)row_off[b] + t) * W4 + c];
+    else if (t >= T - rf) v = reinterpret_cast<const float4*>(edge)[(int64_t)(t - (T - rf)) * W4 + c];
+    else v = reinterpret_cast<const float4*>(quiet)[c];
+    reinterpret_cast<float4*>(dst)[i] = v;
+}
+void launch_unpack_rows_quiet(hipStream_t s, const float* src, const int* valid, const int* row_off, int B, int T, int W, int rf,
+                              const float* quiet, const float* edge, float* dst) {
+    const int64_t n4 = (int64_t)B * T * (W / 4);
+    if (n4 == 0) return;
+    if (W % 4) { fprintf(stderr, "stn: unpack_rows needs W %% 4 == 0\n"); abort(); }
+    STN_KLAUNCH(unpack_rows_quiet_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, valid, row_off, T, W / 4, rf, quiet, edge,
+                n4, dst);
+}
+
 __global__ void mask_ncl_kernel(float* __restrict__ x, int D, int L, int64_t n, const int* __restrict__ len) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -117,3 +117,36 @@ def test_zero_length_utterance_in_a_packed_batch(dtype):
     assert rel_err(outs[True][0], outs[False][0])[0] < 5 * tol
     np.testing.assert_array_equal(outs[True][0][1], outs[True][0][3])  # two silent utterances: identical output
     eng.set_packed_rows(True)
+
+
+def test_trimmed_dense_vocoder_is_bit_identical():
+    """Default (reference) vocoder semantics: the padding is decoded as zero latent.  Where that padding is longer than twice the
+    receptive field the engine computes only len*6 + 114 frames of the utterance and fills the position-independent rest from
+    the model's cached zero-latent response — the returned [B, W] array must equal the dense computation BIT FOR BIT."""
+    a = default_arch()
+    eng = binding.Engine(0, "bf16")
+    eng.load_synthetic(a, 7)
+    rng = np.random.default_rng(3)
+    for case in range(4):
+        B = [6, 3, 12, 3][case]
+        Lt = 48
+        lens = rng.integers(2, Lt + 1, B)
+        lens[0] = Lt
+        ids, mask, sttl, sdp = make_inputs(a, B, Lt, lens, seed=40 + case)
+        durs = rng.uniform(0.1, 1.0, B).astype(np.float32)
+        durs[0] = [4.0, 3.0, 6.0, 4.5][case]  # one long utterance: everybody else gets a long zero-latent tail
+        if case == 3:
+            durs[1] = durs[0] - 0.5  # padding shorter than the receptive fields: this one stays dense, the third is trimmed
+        outs = {}
+        for packed in (False, True):
+            eng.set_packed_rows(packed)
+            for _ in range(3):  # eager, capture, replay
+                w, d = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=durs, noise_seed=9)
+                if packed in outs:
+                    np.testing.assert_array_equal(w, outs[packed][0])
+            B_, L, W = eng.batch_dims()
+            outs[packed] = (w, eng.vo_rows)
+            assert (eng.vo_rows < B * L * 6) == packed, (case, packed, eng.vo_rows, B * L * 6)
+        np.testing.assert_array_equal(outs[True][0], outs[False][0])
+        assert outs[True][1] < outs[False][1]
+    eng.set_packed_rows(True)
