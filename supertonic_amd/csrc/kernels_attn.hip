@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
 // ---------------------------------------------------------------------------------------------
 // bf16 MFMA attention (v_mfma_f32_32x32x16_bf16), head dim DH in {32, 64, 96}.
 //   workgroup = 4 waves = 128 queries of one (b, h); each wave owns 32 queries.
-//   LDS: Q [128][DH] and K [lk_pad][DH] as bf16 rows of DH*2+16 bytes (the +16 makes every ds_read_b128
+//   LDS: Q [128][DH] and a chunk of K [kc <= 128][DH] as bf16 rows of DH*2+16 bytes (the +16 makes every ds_read_b128
 //   16-lane group hit 16 distinct slots), V TRANSPOSED [DH][lk_pad] with rows of lk_pad*2+8 bytes
 //   (conflict-free ds_read_b64 per 32-lane half).  RoPE + 1/sqrt(dh)*log2(e) are applied while staging.
 //   S^T = K Q^T is computed with the KEY on the accumulator rows and the QUERY on the lane, so the row max and
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
 //   of O += P V with no lane movement (registers 8s..8s+7 = k-step s; element j <-> key 16s+8(j>>2)+4h+(j&3),
 //   which is exactly the order the transposed V image is read in).
 //   Softmax is two-pass (max, then exp/sum/PV with QK^T recomputed): sequences are <= ~320 keys, recomputing
-//   the small QK^T is cheaper than rescaling O (whose rows live in registers, not on the lane).
+//   the small QK^T is cheaper than rescaling O (whose rows live in registers, not on the lane).  Contexts longer than
+//   one 128-key chunk stream K through the chunk buffer twice (once per pass) and V once.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -170,16 +171,17 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ q, int ldq,
                                                         const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                         int ldk, uint16_t* __restrict__ o, int ldo, int Lq, int Lk,
-                                                        int lk_pad, const int* __restrict__ qlen,
+                                                        int kc /* keys per LDS chunk: multiple of 32, <= 128 */,
+                                                        const int* __restrict__ qlen,
                                                         const int* __restrict__ klen, int rope_mode, float log_base,
                                                         float gamma, int k_rot, const int* __restrict__ q_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float inv_rev[DH / 2];  // rotation frequency of pair i in REVOLUTIONS per position unit (v_sin/v_cos input)
     constexpr int QS = DH * 2 + 16;  // bytes per Q / K row
-    const int VS = lk_pad * 2 + 8;   // bytes per V^T row
+    const int VS = kc * 2 + 8;       // bytes per V^T row
     unsigned char* Qs = lds_raw;
     unsigned char* Ks = Qs + 128 * QS;
-    unsigned char* Vt = Ks + lk_pad * QS;
+    unsigned char* Vt = Ks + kc * QS;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nk = klen ? min(klen[b], Lk) : Lk;
@@ -190,17 +192,18 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     constexpr int HD2 = DH / 2;
     const float qmul = rsqrtf((float)DH) * 1.44269504088896340736f;
 
-    // ---- stage Q and K (RoPE in fp32, stored bf16): 8 pairs per thread-iteration, 16-byte loads and LDS stores ---------
     if (rope_mode >= 0) {
         for (int i = tid; i < HD2; i += 256) inv_rev[i] = __expf(-log_base * (float)(2 * i) / (float)DH) * 0.15915494309189535f;
         __syncthreads();
     }
     constexpr int CH = HD2 / 8;  // 16-byte chunks per half row
-    for (int pass = 0; pass < 2; ++pass) {
+    // ---- staging of Q (pass 0: 128 rows from q0) or of a chunk of K (pass 1: kc rows from key c0): RoPE in fp32, stored
+    // bf16; 8 pairs per thread-iteration, 16-byte loads and LDS stores ----------------------------------------------------
+    auto stage_rows = [&](int pass, int c0) {
         const uint16_t* src = pass == 0 ? q + h * DH : k + h * DH;
         const int ld = pass == 0 ? ldq : ldk;
         const int64_t seq_base = pass == 0 ? qrow0 : (int64_t)b * Lk;
-        const int pos0 = pass == 0 ? q0 : 0, rows = pass == 0 ? 128 : lk_pad, limit = pass == 0 ? qrows : nk;
+        const int pos0 = pass == 0 ? q0 : c0, rows = pass == 0 ? 128 : kc, limit = pass == 0 ? qrows : nk;
         const int seq_len = pass == 0 ? nq : nk;
         const float mul = pass == 0 ? qmul : 1.f;
         const bool rot = rope_mode >= 0 && !(pass == 1 && k_rot);
@@ -243,89 +246,129 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
             *reinterpret_cast<u32x4_t*>(dst + r * QS + c * 16) = o0;
             *reinterpret_cast<u32x4_t*>(dst + r * QS + HD2 * 2 + c * 16) = o1;
         }
-    }
-    // ---- stage V transposed ------------------------------------------------------------------------------
-    for (int idx = tid; idx < lk_pad * (DH / 8); idx += 256) {
-        const int key = idx / (DH / 8), c = idx - key * (DH / 8);
-        u32x4_t w = {0u, 0u, 0u, 0u};
-        if (key < nk) w = *reinterpret_cast<const u32x4_t*>(v + ((int64_t)b * Lk + key) * ldk + h * DH + c * 8);
+    };
+    // ---- a chunk of V, transposed ---------------------------------------------------------------------------------------
+    auto stage_v = [&](int c0) {
+        for (int idx = tid; idx < kc * (DH / 8); idx += 256) {
+            const int kl = idx / (DH / 8), c = idx - kl * (DH / 8);
+            const int key = c0 + kl;
+            u32x4_t w = {0u, 0u, 0u, 0u};
+            if (key < nk) w = *reinterpret_cast<const u32x4_t*>(v + ((int64_t)b * Lk + key) * ldk + h * DH + c * 8);
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-            const unsigned word = w[e2];
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2) * VS + key * 2) = (uint16_t)(word & 0xFFFFu);
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2 + 1) * VS + key * 2) = (uint16_t)(word >> 16);
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const unsigned word = w[e2];
+                *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2) * VS + kl * 2) = (uint16_t)(word & 0xFFFFu);
+                *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2 + 1) * VS + kl * 2) = (uint16_t)(word >> 16);
+            }
         }
-    }
-    __syncthreads();
+    };
+
     const int qbase = wave * 32;
-    if (q0 + qbase >= qrows) return;  // this wave's 32 queries are all padding (no barrier follows)
-
+    const bool active = q0 + qbase < qrows;  // waves whose 32 queries are all padding still stage and keep the barriers
     const int lr = lane & 31, lh = lane >> 5;
+    const int nkt = kc >> 5;
+    const int nch = nk > 0 ? (nk + kc - 1) / kc : 1;  // key chunks (uniform per workgroup)
     bf16x8_t bq[DH / 16];
-#pragma unroll
-    for (int ks = 0; ks < DH / 16; ++ks)
-        bq[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + (qbase + lr) * QS + (ks * 2 + lh) * 16);
-
-    const int nkt = lk_pad >> 5;
-    float m = -1e30f;
-    for (int kt = 0; kt < nkt; ++kt) {
-        f32x16_t acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < DH / 16; ++ks) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            m = fmaxf(m, key < nk ? acc[i] : -1e30f);
-        }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-
-    float lsum = 0.f;
+    float m = -1e30f, lsum = 0.f;
     f32x16_t oacc[DH / 32];
 #pragma unroll
     for (int nd = 0; nd < DH / 32; ++nd)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[nd][i] = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
-        f32x16_t acc;
+
+    auto load_q = [&]() {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int ks = 0; ks < DH / 16; ++ks)
+            bq[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + (qbase + lr) * QS + (ks * 2 + lh) * 16);
+    };
+    auto pass_max = [&](int c0) {  // running row maximum over the staged chunk
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (c0 + kt * 32 >= nk) break;
+            f32x16_t acc;
 #pragma unroll
-        for (int ks = 0; ks < DH / 16; ++ks) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
-        }
-        float p[16];
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            p[i] = key < nk ? exp2f(acc[i] - m) : 0.f;
-            lsum += p[i];
-        }
+            for (int ks = 0; ks < DH / 16; ++ks) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+            }
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            u32x4_t pw;
-            pw[0] = pack_bf16x2(p[8 * sidx + 0], p[8 * sidx + 1]);
-            pw[1] = pack_bf16x2(p[8 * sidx + 2], p[8 * sidx + 3]);
-            pw[2] = pack_bf16x2(p[8 * sidx + 4], p[8 * sidx + 5]);
-            pw[3] = pack_bf16x2(p[8 * sidx + 6], p[8 * sidx + 7]);
-            const bf16x8_t ap = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-            for (int nd = 0; nd < DH / 32; ++nd) {
-                const unsigned char* base = Vt + (nd * 32 + lr) * VS + (kt * 32 + 16 * sidx + 4 * lh) * 2;
-                const uint2 lo = *reinterpret_cast<const uint2*>(base);
-                const uint2 hi = *reinterpret_cast<const uint2*>(base + 16);
-                u32x4_t vw;
-                vw[0] = lo.x; vw[1] = lo.y; vw[2] = hi.x; vw[3] = hi.y;
-                oacc[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                const int key = c0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                m = fmaxf(m, key < nk ? acc[i] : -1e30f);
             }
         }
+    };
+    auto pass_pv = [&](int c0) {  // exp, row sums and P V over the staged chunk (QK^T recomputed)
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (c0 + kt * 32 >= nk) break;
+            f32x16_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < DH / 16; ++ks) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+            }
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = c0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                p[i] = key < nk ? exp2f(acc[i] - m) : 0.f;
+                lsum += p[i];
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                u32x4_t pw;
+                pw[0] = pack_bf16x2(p[8 * sidx + 0], p[8 * sidx + 1]);
+                pw[1] = pack_bf16x2(p[8 * sidx + 2], p[8 * sidx + 3]);
+                pw[2] = pack_bf16x2(p[8 * sidx + 4], p[8 * sidx + 5]);
+                pw[3] = pack_bf16x2(p[8 * sidx + 6], p[8 * sidx + 7]);
+                const bf16x8_t ap = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+                for (int nd = 0; nd < DH / 32; ++nd) {
+                    const unsigned char* base = Vt + (nd * 32 + lr) * VS + (kt * 32 + 16 * sidx + 4 * lh) * 2;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(base);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(base + 16);
+                    u32x4_t vw;
+                    vw[0] = lo.x; vw[1] = lo.y; vw[2] = hi.x; vw[3] = hi.y;
+                    oacc[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    stage_rows(0, 0);
+    if (nch == 1) {  // the whole context fits one chunk: K is staged once and serves both passes
+        stage_rows(1, 0);
+        stage_v(0);
+        __syncthreads();
+        if (active) {
+            load_q();
+            pass_max(0);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            pass_pv(0);
+        }
+    } else {  // long contexts (up to ~320 text tokens): K streams through the chunk buffer twice, V once
+        for (int c = 0; c < nch; ++c) {
+            if (c) __syncthreads();  // every wave is done with the previous chunk
+            stage_rows(1, c * kc);
+            __syncthreads();
+            if (active) {
+                if (c == 0) load_q();
+                pass_max(c * kc);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();
+            stage_rows(1, c * kc);
+            stage_v(c * kc);
+            __syncthreads();
+            if (active) pass_pv(c * kc);
+        }
     }
+    if (!active) return;
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = (nk > 0 && lsum > 0.f) ? 1.0f / lsum : 0.f;
 #pragma unroll
@@ -343,7 +386,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 
 template <int DH>
 static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
-                             uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int lk_pad, size_t lds, const int* qlen,
+                             uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int kc, size_t lds, const int* qlen,
                              const int* klen, int rope_mode, float log_base, float gamma, int k_rot, const int* q_off) {
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
@@ -351,7 +394,7 @@ static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const ui
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(attn_mfma)");
     }
     const dim3 grid((Lq + 127) / 128, H, B);
-    STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, lk_pad, qlen, klen,
+    STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, kc, qlen, klen,
                        rope_mode, log_base, gamma, k_rot, q_off);
 }
 
@@ -363,17 +406,18 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
     if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
         !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
+        // keys go through LDS in chunks of at most 128 (one chunk covers the 50 style tokens and ~100-token texts; longer texts
+        // take several), so the MFMA kernel serves every context length at 2 workgroups per CU
         const int lk_pad = (Lk + 31) & ~31;
-        const size_t need = (size_t)128 * (dh * 2 + 16) + (size_t)lk_pad * (dh * 2 + 16) + (size_t)dh * (lk_pad * 2 + 8);
-        if (need <= 150 * 1024) {
-            const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
-            uint16_t* o16 = static_cast<uint16_t*>(o);
-            const float lb = logf(rope_base);
-            if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
-            else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
-            else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, lk_pad, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
-            return;
-        }
+        const int kc = lk_pad < 128 ? lk_pad : 128;
+        const size_t need = (size_t)128 * (dh * 2 + 16) + (size_t)kc * (dh * 2 + 16) + (size_t)dh * (kc * 2 + 8);
+        const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
+        uint16_t* o16 = static_cast<uint16_t*>(o);
+        const float lb = logf(rope_base);
+        if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
+        else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
+        else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
+        return;
     }
     const int ds = dh + 1;
     const size_t lds = sizeof(float) * ((size_t)(AQ + 2 * AK) * ds + (size_t)AQ * (AK + 1));

@@ -101,7 +101,9 @@ def test_dwconv_ln(eng, C, k, dil, B, L):
 
 
 @pytest.mark.parametrize("dh,H,Lq,Lk,rope", [(32, 2, 7, 11, -1), (64, 4, 70, 70, 0), (96, 4, 49, 62, 1), (48, 2, 33, 130, 1),
-                                              (16, 2, 5, 6, 0), (64, 4, 200, 310, 0), (96, 2, 130, 50, -1), (32, 4, 129, 33, 1)])
+                                              (16, 2, 5, 6, 0), (64, 4, 200, 310, 0), (96, 2, 130, 50, -1), (32, 4, 129, 33, 1),
+                                              # long contexts: keys stream through LDS in 128-key chunks (3 chunks here), partial last chunk
+                                              (96, 4, 78, 311, 1), (96, 2, 140, 257, 0), (32, 2, 40, 129, -1)])
 def test_attention(eng, dh, H, Lq, Lk, rope):
     rng = np.random.default_rng(dh + Lq + Lk)
     B, C = 2, dh * H
