@@ -445,8 +445,9 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
 
 // x <- (x + Wo attn(LN(x) Wq, ctx Wk, ctx Wv)) * mask.   self: ctx = LN(x), one fused QKV GEMM.
 void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
-                        const int* klen, int rope_mode, bool self) {
-    const int64_t Mq = (int64_t)B * Lq, Mk = (int64_t)B * Lk;
+                        const int* klen, int rope_mode, bool self, const Ragged* qrg) {
+    // qrg: the query rows (and, for self-attention, the key rows too) are packed; a cross-attention context stays dense
+    const int64_t Mq = qrg ? (int64_t)qrg->rows : (int64_t)B * Lq, Mk = (int64_t)B * Lk;
     const Arena::Mark mk = ar_.mark();
     const size_t esz = dt_ == BF16 ? 2 : 4;
     void* xn = act_alloc(Mq * C);
@@ -474,9 +475,10 @@ void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, co
     }
     void* o = act_alloc(Mq * C);
     if (prof_on_) prof_begin("attention", 4.0 * Mq * (double)Lk * C, (double)(Mq * 2 + Mk * 2) * C * esz);
-    launch_attention(s_, dt_, q, ldq, k, v, ldk, o, C, B, Lq, Lk, H, C / H, qlen, klen, rope_mode, a_.rope_base, a_.larope_gamma);
+    launch_attention(s_, dt_, q, ldq, k, v, ldk, o, C, B, Lq, Lk, H, C / H, qlen, klen, rope_mode, a_.rope_base, a_.larope_gamma,
+                     false, qrg ? qrg->off : nullptr, (qrg && self) ? qrg->off : nullptr);
     if (prof_on_) prof_end();
-    Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = qlen; eo.L = Lq;
+    Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = qrg ? nullptr : qlen; eo.L = Lq;
     gemm("gemm_attn_out", dt_, o, C, p.o, (int)Mq, eo);
     ar_.release(mk);
 }
@@ -484,23 +486,24 @@ void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, co
 // =================================================================================================
 // stages (device level)
 // =================================================================================================
-void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur) {
+void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur, const Ragged* trg) {
     stage_ = "dp";
     const stn_arch& a = a_;
     const int C = a.dp_dim;
-    const int64_t M = (int64_t)B * Lt;
+    const int64_t M = trg ? (int64_t)trg->rows : (int64_t)B * Lt;
+    const int* toff = trg ? trg->off : nullptr;
     const Arena::Mark mk = ar_.mark();
     float* x = f32_alloc(M * C);
-    launch_embed(s_, ids, vecf("dp.emb"), a.vocab_size, B, Lt, C, tlen, x);
+    launch_embed(s_, ids, vecf("dp.emb"), a.vocab_size, B, Lt, C, tlen, x, toff);
     for (int i = 0; i < a.dp_conv_blocks; ++i)
-        convnext(convnext_w("dp.conv" + std::to_string(i)), x, B, Lt, C, a.dp_hidden, a.dp_kernel, 1, tlen);
+        convnext(convnext_w("dp.conv" + std::to_string(i)), x, B, Lt, C, a.dp_hidden, a.dp_kernel, 1, tlen, nullptr, nullptr, 0, trg);
     void* st = to_act(style_dp, (int64_t)B * a.n_style_dp * a.d_style_dp);
-    attn_block(attn_w("dp.st", false), x, B, Lt, C, a.dp_heads, st, a.n_style_dp, tlen, nullptr, -1, false);
+    attn_block(attn_w("dp.st", false), x, B, Lt, C, a.dp_heads, st, a.n_style_dp, tlen, nullptr, -1, false, trg);
     float* xn = f32_alloc(M * C);
     const LNorm ln = lnorm("dp.out_ln");
     launch_layernorm(s_, F32, x, M, C, ln.g, ln.b, a.ln_eps, xn);
     float* pooled = f32_alloc((int64_t)B * C);
-    launch_masked_mean(s_, F32, xn, B, Lt, C, tlen, pooled);
+    launch_masked_mean(s_, F32, xn, B, Lt, C, tlen, pooled, toff);
     float* h = f32_alloc((int64_t)B * C);
     Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = F32; e1.out = h; e1.ldo = C;
     gemm("gemm_small_f32", F32, pooled, C, linear("dp.fc1"), B, e1);
@@ -511,19 +514,21 @@ void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_
 }
 
 void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl,
-                          void* rows) {
+                          void* rows, const Ragged* trg) {
     stage_ = "te";
     const stn_arch& a = a_;
     const int C = a.te_dim, Ce = a.te_out_dim;
-    const int64_t M = (int64_t)B * Lt;
+    if (trg && ncl) throw std::runtime_error("text_enc_dev: the [B,Ce,Lt] output needs the padded layout");
+    const int64_t M = trg ? (int64_t)trg->rows : (int64_t)B * Lt;
+    const int* rmask = trg ? nullptr : tlen;  // packed rows need no row mask
     const Arena::Mark mk = ar_.mark();
     float* x = f32_alloc(M * C);
-    launch_embed(s_, ids, vecf("te.emb"), a.vocab_size, B, Lt, C, tlen, x);
+    launch_embed(s_, ids, vecf("te.emb"), a.vocab_size, B, Lt, C, tlen, x, trg ? trg->off : nullptr);
     for (int i = 0; i < a.te_conv_blocks; ++i)
-        convnext(convnext_w("te.conv" + std::to_string(i)), x, B, Lt, C, a.te_hidden, a.te_kernel, 1, tlen);
+        convnext(convnext_w("te.conv" + std::to_string(i)), x, B, Lt, C, a.te_hidden, a.te_kernel, 1, tlen, nullptr, nullptr, 0, trg);
     for (int i = 0; i < a.te_attn_blocks; ++i) {
         const std::string p = "te.sa" + std::to_string(i);
-        attn_block(attn_w(p, true), x, B, Lt, C, a.te_heads, nullptr, Lt, tlen, tlen, 0, true);
+        attn_block(attn_w(p, true), x, B, Lt, C, a.te_heads, nullptr, Lt, tlen, tlen, 0, true, trg);
         const Arena::Mark m2 = ar_.mark();
         void* xn = act_alloc(M * C);
         void* u = act_alloc(M * a.te_ffn);
@@ -531,14 +536,14 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
         launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
         Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = a.te_ffn;
         gemm("gemm_pw1_gelu", dt_, xn, C, linear(p + ".ffn1"), (int)M, e1);
-        Epilogue e2; e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.len = tlen; e2.L = Lt;
+        Epilogue e2; e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.len = rmask; e2.L = Lt;
         gemm("gemm_pw2_resid", dt_, u, a.te_ffn, linear(p + ".ffn2"), (int)M, e2);
         ar_.release(m2);
     }
     void* st = to_act(style_ttl, (int64_t)B * a.n_style_ttl * a.d_style_ttl);
     for (int i = 0; i < a.te_style_blocks; ++i)
         attn_block(attn_w("te.st" + std::to_string(i), false), x, B, Lt, C, a.te_heads, st, a.n_style_ttl, tlen, nullptr,
-                   -1, false);
+                   -1, false, trg);
     void* xn = act_alloc(M * C);
     const LNorm ln = lnorm("te.out_ln");
     launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
@@ -548,7 +553,7 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
         gemm("gemm_proj", dt_, xn, C, proj, (int)M, e);
     }
     if (rows) {
-        Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = rows; e.ldo = Ce; e.len = tlen; e.L = Lt;
+        Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = rows; e.ldo = Ce; e.len = rmask; e.L = Lt;
         gemm("gemm_proj", dt_, xn, C, proj, (int)M, e);
     }
     ar_.release(mk);
@@ -556,19 +561,22 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
 
 // K/V of the text and style contexts for every main block: invariant across Euler steps.
 // The returned buffers live in the arena ABOVE the caller's mark: the caller releases them.
-Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen) {
+Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen, const Ragged* trg) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, nb = a.ve_main_blocks;
     VeCtx c;
     c.Lt = Lt;
-    c.text_kv = act_alloc((int64_t)B * Lt * nb * 2 * C);
+    const int64_t Mt = trg ? (int64_t)trg->rows : (int64_t)B * Lt;  // text rows: packed or padded
+    c.text_off = trg ? trg->off : nullptr;
+    c.text_kv = act_alloc(Mt * nb * 2 * C);
     c.style_kv = act_alloc((int64_t)B * a.n_style_ttl * nb * 2 * C);
     Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = c.text_kv; e.ldo = nb * 2 * C;
-    gemm("gemm_kv", dt_, text_rows, a.te_out_dim, linear("ve.text_kv_all"), B * Lt, e);
+    gemm("gemm_kv", dt_, text_rows, a.te_out_dim, linear("ve.text_kv_all"), (int)Mt, e);
     // LARoPE of the text keys does not depend on the Euler step or on the query: rotate all blocks' keys once
     // (was re-done by every one of the main_blocks x total_step attention launches)
-    launch_rope_rows(s_, dt_, c.text_kv, nb * 2 * C, B, Lt, tlen, nb, 2 * C, a.ve_heads, C / a.ve_heads, 1, a.rope_base, a.larope_gamma);
+    launch_rope_rows(s_, dt_, c.text_kv, nb * 2 * C, B, Lt, tlen, nb, 2 * C, a.ve_heads, C / a.ve_heads, 1, a.rope_base, a.larope_gamma,
+                     c.text_off);
     void* st = to_act(style_ttl, (int64_t)B * a.n_style_ttl * a.d_style_ttl);
     Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = dt_; e2.out = c.style_kv; e2.ldo = nb * 2 * C;
     gemm("gemm_kv", dt_, st, a.d_style_ttl, linear("ve.style_kv_all"), B * a.n_style_ttl, e2);
@@ -628,7 +636,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         void* o = act_alloc(M * C);
         if (prof_on_) prof_begin("attention", 4.0 * M * (double)Lk * C, (double)(M * 2 + (int64_t)B * Lk * 2) * C * esz);
         launch_attention(s_, dt_, qb, C, kp, vp, nb * 2 * C, o, C, B, L, Lk, H, C / H, llen, klen, rope_mode, a.rope_base,
-                         a.larope_gamma, /*k_rotated=*/rope_mode >= 0, roff);
+                         a.larope_gamma, /*k_rotated=*/rope_mode >= 0, roff, kv_all == c.text_kv ? c.text_off : nullptr);
         if (prof_on_) prof_end();
         Epilogue eo; eo.mode = EPI_RESID; eo.resid = x; eo.ldo = C; eo.len = rmask; eo.L = L;
         gemm("gemm_attn_out", dt_, o, C, w.o, (int)M, eo);
@@ -902,6 +910,15 @@ void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_m
     ar_.reset();
     float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt);
     launch_mask_to_len(s_, d_mask, B, Lt, b.tlen);
+    // packed text rows: first row of each utterance (fixed for the life of this upload) and their total
+    ensure(b.toff, b.toff_cap, (size_t)B + 1);
+    b.trows = 0;
+    for (int i = 0; i < B; ++i) {
+        int n = 0;
+        for (int t = 0; t < Lt; ++t) n += text_mask[(size_t)i * Lt + t] > 0.5f ? 1 : 0;  // as mask_to_len_kernel counts
+        b.trows += n;
+    }
+    if (B <= 1024) launch_row_map(s_, b.tlen, B, b.toff, nullptr);
     b.have_override = duration_override != nullptr;
     if (duration_override) b.h_dur.assign(duration_override, duration_override + B);
     sync();
@@ -947,7 +964,10 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     b.total_step = total_step; b.speed = speed; b.noise_seed = noise_seed;
     ar_.reset();
     // 1. duration predictor (always executed; its output may be overridden for shape control)
-    duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur);
+    Ragged trg;
+    const bool tpk = packed_text_ok(B) && b.trows > 0;
+    if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
+    duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
     std::vector<float> dur(B);
     if (b.have_override) {
         dur = b.h_dur;  // known on the host: no device->host read, no sync
@@ -994,6 +1014,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;
     last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L;
     key.vrows = trimmed_rows(B, L, nullptr);
+    key.trows = tpk ? b.trows : 0;
     last_vo_rows_ = (int64_t)B * L * a.chunk_compress_factor;
     if (vo_ragged_ && packed_ve_ && dt_ == BF16) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
     else if (key.vrows) last_vo_rows_ = key.vrows; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
@@ -1042,8 +1063,12 @@ void Engine::enqueue_after_duration(int total_step) {
     STN_HIP(hipMemcpyAsync(b.llen, pin_llen_, sizeof(int) * B, hipMemcpyHostToDevice, s_));
     STN_HIP(hipMemcpyAsync(seed_dev_, pin_seed_, sizeof(unsigned long long), hipMemcpyHostToDevice, s_));
     // 2. text encoder -> context rows (act dtype)
-    void* text_rows = act_alloc((int64_t)B * Lt * a.te_out_dim);
-    text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, text_rows);
+    Ragged trg;
+    const bool tpk = packed_text_ok(B) && b.trows > 0;
+    if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
+    const Ragged* trgp = tpk ? &trg : nullptr;
+    void* text_rows = act_alloc((tpk ? (int64_t)b.trows : (int64_t)B * Lt) * a.te_out_dim);
+    text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, text_rows, trgp);
     // 3. initial latent
     if (b.have_noise) {
         STN_HIP(hipMemcpyAsync(b.xt[0], b.noise, nx * 4, hipMemcpyDeviceToDevice, s_));
@@ -1052,7 +1077,7 @@ void Engine::enqueue_after_duration(int total_step) {
         launch_randn_masked(s_, 0, b.utt_ids, B, D, L, b.llen, b.xt[0], seed_dev_);
     }
     // 4. Euler loop: step-invariant K/V once, the time conditioning of every step in one pass, then total_step passes
-    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen);
+    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen, trgp);
     float* tot_all = f32_alloc((int64_t)total_step * B);
     float* cur_all = f32_alloc((int64_t)total_step * B);
     launch_fill(s_, tot_all, total_step * B, (float)total_step);

@@ -83,12 +83,15 @@ class Engine {
 
     // ---- device-level stages (all pointers device, enqueued on stream()) -------------------------
     // lengths are int32 [B] on device.
-    void duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur);
+    struct Ragged;  // packed rows (defined below)
+    // trg (optional): the text positions as packed rows (sum of tlen rows, off[b] = first row of utterance b)
+    void duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur, const Ragged* trg = nullptr);
     // emits text_emb as NCL fp32 [B,Ce,Lt] (if ncl) and/or as rows [B*Lt][Ce] in the act dtype (if rows)
-    void text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl, void* rows);
-    struct VeCtx { void* text_kv = nullptr; void* style_kv = nullptr; int Lt = 0; };  // step-invariant K/V
+    void text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_ttl, const int* tlen, float* ncl, void* rows,
+                      const Ragged* trg = nullptr);
+    struct VeCtx { void* text_kv = nullptr; void* style_kv = nullptr; int Lt = 0; const int* text_off = nullptr; };  // step-invariant K/V
     // tlen: text lengths (the text keys are rotated here, once, with their length-aware positions)
-    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen);
+    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen, const Ragged* trg = nullptr);
     // time conditioning of `rows` (= B x steps) (current, total) pairs -> tb [rows][main_blocks * C] (fp32, arena)
     float* ve_time_cond_dev(int rows, const float* total_step, const float* current_step);
     // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
@@ -134,6 +137,8 @@ class Engine {
         float* xt[2] = {nullptr, nullptr}; size_t xt_cap[2] = {0, 0};
         float* wav = nullptr; size_t wav_cap = 0;        // [B, L*cs]
         int16_t* pcm = nullptr; size_t pcm_cap = 0;      // [B, L*cs] int16 (on demand)
+        int* toff = nullptr; size_t toff_cap = 0;       // packed text rows: first row of each utterance [B+1]
+        int trows = 0;                                   // sum of the text lengths
         uint64_t gen = 0;
         std::vector<float> h_dur; std::vector<int> h_llen;
     };
@@ -150,6 +155,9 @@ class Engine {
     void set_packed_rows(bool on) { packed_ve_ = on; }
     int64_t last_ve_rows() const { return last_ve_rows_; }
     int64_t last_vo_rows() const { return last_vo_rows_; }  // frames the vocoder computed in the last batch_run  // rows the estimator worked on in the last batch_run
+    bool packed_text_ok(int B) const {
+        return packed_ve_ && B <= 1024 && dwconv_ln_supports_packed(a_.te_dim, a_.te_kernel) && dwconv_ln_supports_packed(a_.dp_dim, a_.dp_kernel);
+    }
     bool packed_rows_ok(int B) const { return packed_ve_ && B <= 1024 && a_.ve_dilated > 0 && dwconv_ln_supports_packed(a_.ve_dim, a_.ve_kernel); }
     long graph_replays() const { return graph_replays_; }
     const Batch& batch() const { return bt_; }
@@ -204,7 +212,7 @@ class Engine {
     void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
                   const int* conv_len = nullptr, const float* rowvec = nullptr, int rv_ld = 0, const Ragged* rg = nullptr);
     void attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
-                    const int* klen, int rope_mode, bool self);
+                    const int* klen, int rope_mode, bool self, const Ragged* qrg = nullptr);
     void* to_act(const float* src, int64_t n);
 
     struct ProfSpan { std::string tag; hipEvent_t a, b; double flops, bytes; };
@@ -229,8 +237,8 @@ class Engine {
     std::vector<float> reported_dur_;
     void enqueue_after_duration(int total_step);
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int rows = 0, vrows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
-        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && rows == o.rows && vrows == o.vrows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int rows = 0, vrows = 0, trows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && rows == o.rows && vrows == o.vrows && trows == o.trows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
     };
     bool graph_on_ = true;
     bool vo_ragged_ = false;

@@ -99,17 +99,18 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
                       float rope_base, float rope_gamma, bool k_rotated = false,
-                      const int* q_off = nullptr /* packed query/output rows: sequence b starts at q_off[b], owns qlen[b] */);
+                      const int* q_off = nullptr /* packed query/output rows: sequence b starts at q_off[b], owns qlen[b] */,
+                      const int* k_off = nullptr /* packed key/value rows: sequence b starts at k_off[b], owns klen[b] */);
 // in-place RoPE of `groups` key blocks per row: element (row b*L+t, column g*group_stride + h*dh + i) for t < len[b]
 // (len null: all rows).  Keys that are reused by many attention launches (the vector estimator's text keys: every
 // block of every Euler step) are rotated once here instead of at every launch.  Same arithmetic as the attention
 // kernels' staging (fp32 rotation, one rounding to the storage dtype).
 void launch_rope_rows(hipStream_t s, int dtype, void* x, int ld, int B, int L, const int* len, int groups, int group_stride,
-                      int H, int dh, int rope_mode, float rope_base, float rope_gamma);
+                      int H, int dh, int rope_mode, float rope_base, float rope_gamma, const int* row_off = nullptr /* packed rows */);
 
 // embedding gather: x[b*L+t][:] = (t < len[b] && 0 <= id < vocab) ? emb[id][:] : 0     (fp32 out)
 void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab, int B, int L, int C, const int* len,
-                  float* x);
+                  float* x, const int* row_off = nullptr /* packed destination rows */);
 // prefix mask [B][L] (float) -> len[B] (count of entries > 0.5)
 void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len);
 // [B][C][L] fp32 -> rows [B*L][ld_out] act (columns C..ld_out-1 are zero-filled: K padding for the GEMM that follows)
@@ -140,7 +141,8 @@ void launch_trim_len(hipStream_t s, const int* len, int B, int ccf, int T, int r
 void launch_unpack_rows_quiet(hipStream_t s, const float* src, const int* valid, const int* row_off, int B, int T, int W, int rf,
                               const float* quiet, const float* edge, float* dst);
 // masked mean over valid rows: pooled[b][c] = sum_{t<len[b]} x[b*L+t][c] / max(len[b],1)   (x act dtype, out fp32)
-void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled);
+void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled,
+                        const int* row_off = nullptr /* packed source rows */);
 // y = softplus(x) elementwise (n small)
 void launch_softplus(hipStream_t s, float* x, int n);
 // durations: d[b] = (override ? override[b] : d[b]) / speed ; computes per-b latent length; see engine

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
                                                    const T* __restrict__ v, int ldk, T* __restrict__ o, int ldo, int Lq,
                                                    int Lk, int dh, const int* __restrict__ qlen,
                                                    const int* __restrict__ klen, int rope_mode, float log_base,
-                                                   float gamma, int k_rot, const int* __restrict__ q_off) {
+                                                   float gamma, int k_rot, const int* __restrict__ q_off,
+                                                   const int* __restrict__ k_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ds = dh + 1;
     float* Qs = lds;               // [AQ][ds]
@@ -85,8 +86,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
 
     for (int k0 = 0; k0 < nk; k0 += AK) {
         __syncthreads();  // previous tile fully consumed (and Qs visible on the first pass)
-        stage_rows<T>(k + h * dh, ldk, (int64_t)b * Lk, k0, AK, nk, dh, ds, Ks, k_rot ? -1 : rope_mode, log_base, gamma, nk, 1.f);
-        stage_rows<T>(v + h * dh, ldk, (int64_t)b * Lk, k0, AK, nk, dh, ds, Vs, -1, 0.f, 0.f, 1, 1.f);
+        const int64_t krow0 = k_off ? (int64_t)k_off[b] : (int64_t)b * Lk;
+        stage_rows<T>(k + h * dh, ldk, krow0, k0, AK, nk, dh, ds, Ks, k_rot ? -1 : rope_mode, log_base, gamma, nk, 1.f);
+        stage_rows<T>(v + h * dh, ldk, krow0, k0, AK, nk, dh, ds, Vs, -1, 0.f, 0.f, 1, 1.f);
         __syncthreads();
         float s[8];
 #pragma unroll
@@ -174,7 +176,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                                                         int kc /* keys per LDS chunk: multiple of 32, <= 128 */,
                                                         const int* __restrict__ qlen,
                                                         const int* __restrict__ klen, int rope_mode, float log_base,
-                                                        float gamma, int k_rot, const int* __restrict__ q_off) {
+                                                        float gamma, int k_rot, const int* __restrict__ q_off,
+                                                        const int* __restrict__ k_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float inv_rev[DH / 2];  // rotation frequency of pair i in REVOLUTIONS per position unit (v_sin/v_cos input)
     constexpr int QS = DH * 2 + 16;  // bytes per Q / K row
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     const int64_t qrow0 = q_off ? (int64_t)q_off[b] : (int64_t)b * Lq;  // packed: the sequence owns nq rows from q_off[b]
     const int qrows = q_off ? nq : Lq;
     if (q0 >= qrows) return;  // uniform: nothing of this tile exists
+    const int64_t krow0 = k_off ? (int64_t)k_off[b] : (int64_t)b * Lk;  // packed keys: the sequence owns nk rows from k_off[b]
     constexpr int HD2 = DH / 2;
     const float qmul = rsqrtf((float)DH) * 1.44269504088896340736f;
 
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     auto stage_rows = [&](int pass, int c0) {
         const uint16_t* src = pass == 0 ? q + h * DH : k + h * DH;
         const int ld = pass == 0 ? ldq : ldk;
-        const int64_t seq_base = pass == 0 ? qrow0 : (int64_t)b * Lk;
+        const int64_t seq_base = pass == 0 ? qrow0 : krow0;
         const int pos0 = pass == 0 ? q0 : c0, rows = pass == 0 ? 128 : kc, limit = pass == 0 ? qrows : nk;
         const int seq_len = pass == 0 ? nq : nk;
         const float mul = pass == 0 ? qmul : 1.f;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
             const int kl = idx / (DH / 8), c = idx - kl * (DH / 8);
             const int key = c0 + kl;
             u32x4_t w = {0u, 0u, 0u, 0u};
-            if (key < nk) w = *reinterpret_cast<const u32x4_t*>(v + ((int64_t)b * Lk + key) * ldk + h * DH + c * 8);
+            if (key < nk) w = *reinterpret_cast<const u32x4_t*>(v + (krow0 + key) * ldk + h * DH + c * 8);
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
                 const unsigned word = w[e2];
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 template <int DH>
 static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
                              uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int kc, size_t lds, const int* qlen,
-                             const int* klen, int rope_mode, float log_base, float gamma, int k_rot, const int* q_off) {
+                             const int* klen, int rope_mode, float log_base, float gamma, int k_rot, const int* q_off, const int* k_off) {
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
         // 150 KiB dynamic (the launcher's own bound) + the kernel's static table stay inside the CU's 160 KiB
@@ -395,14 +399,14 @@ static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const ui
     }
     const dim3 grid((Lq + 127) / 128, H, B);
     STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, kc, qlen, klen,
-                       rope_mode, log_base, gamma, k_rot, q_off);
+                       rope_mode, log_base, gamma, k_rot, q_off, k_off);
 }
 
 void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const void* k, const void* v, int ldk, void* o,
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
-                      float rope_base, float rope_gamma, bool k_rotated, const int* q_off) {
+                      float rope_base, float rope_gamma, bool k_rotated, const int* q_off, const int* k_off) {
     if (B == 0 || Lq == 0) return;
-    if (q_off && !qlen) { fprintf(stderr, "stn: packed attention needs query lengths\n"); abort(); }
+    if ((q_off && !qlen) || (k_off && !klen)) { fprintf(stderr, "stn: packed attention needs the lengths of the packed side\n"); abort(); }
     if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
     if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
         !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
@@ -414,9 +418,9 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
         const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
         uint16_t* o16 = static_cast<uint16_t*>(o);
         const float lb = logf(rope_base);
-        if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
-        else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
-        else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off);
+        if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off);
+        else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off);
+        else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off);
         return;
     }
     const int ds = dh + 1;
@@ -431,11 +435,11 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (dtype == BF16)
         STN_KLAUNCH(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
                            static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), ldk, static_cast<uint16_t*>(o), ldo,
-                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off);
+                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
     else
         STN_KLAUNCH(attn_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(q), ldq,
                            static_cast<const float*>(k), static_cast<const float*>(v), ldk, static_cast<float*>(o), ldo, Lq, Lk,
-                           dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off);
+                           dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,7 +447,8 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void rope_rows_kernel(T* __restrict__ x, int ld, int L, const int* __restrict__ len, int groups, int group_stride,
-                                 int H, int dh, int rope_mode, float log_base, float gamma, int64_t n) {
+                                 int H, int dh, int rope_mode, float log_base, float gamma, int64_t n,
+                                 const int* __restrict__ row_off) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B*L][groups][H][dh/2]
     if (idx >= n) return;
     const int hd2 = dh >> 1;
@@ -454,7 +459,8 @@ __global__ void rope_rows_kernel(T* __restrict__ x, int ld, int L, const int* __
     const int pos = (int)(r % L), b = (int)(r / L);
     const int nb = len ? min(len[b], L) : L;
     if (pos >= nb) return;
-    T* p = x + r * ld + (int64_t)g * group_stride + h * dh;
+    const int64_t row = row_off ? (int64_t)row_off[b] + pos : r;  // packed rows: position pos of sequence b
+    T* p = x + row * ld + (int64_t)g * group_stride + h * dh;
     const float a0 = ld_act(p + i), a1 = ld_act(p + i + hd2);
     const float pp = rope_mode == 1 ? gamma * (float)pos / (float)(nb > 0 ? nb : 1) : (float)pos;
     const float inv = expf(-log_base * (float)(2 * i) / (float)dh);
@@ -465,16 +471,16 @@ __global__ void rope_rows_kernel(T* __restrict__ x, int ld, int L, const int* __
 }
 
 void launch_rope_rows(hipStream_t s, int dtype, void* x, int ld, int B, int L, const int* len, int groups, int group_stride,
-                      int H, int dh, int rope_mode, float rope_base, float rope_gamma) {
+                      int H, int dh, int rope_mode, float rope_base, float rope_gamma, const int* row_off) {
     const int64_t n = (int64_t)B * L * groups * H * (dh / 2);
     if (n == 0 || rope_mode < 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
     if (dtype == BF16)
         STN_KLAUNCH(rope_rows_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<uint16_t*>(x), ld, L, len, groups,
-                           group_stride, H, dh, rope_mode, logf(rope_base), rope_gamma, n);
+                           group_stride, H, dh, rope_mode, logf(rope_base), rope_gamma, n, row_off);
     else
         STN_KLAUNCH(rope_rows_kernel<float>, grid, dim3(256), 0, s, static_cast<float*>(x), ld, L, len, groups, group_stride,
-                           H, dh, rope_mode, logf(rope_base), rope_gamma, n);
+                           H, dh, rope_mode, logf(rope_base), rope_gamma, n, row_off);
 }
 
 }  // namespace stn

@@ -405,12 +405,13 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
 // small helpers
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb, int vocab, int L, int C,
-                             const int* __restrict__ len, float* __restrict__ x) {
+                             const int* __restrict__ len, float* __restrict__ x, const int* __restrict__ row_off) {
     const int row = blockIdx.x, b = row / L, t = row - b * L;
+    if (row_off && t >= len[b]) return;  // packed destination: the position does not exist
     const int64_t id = ids[row];
     const bool ok = t < len[b] && id >= 0 && id < vocab;
     const int C4 = C >> 2;
-    float4* o = reinterpret_cast<float4*>(x) + (int64_t)row * C4;
+    float4* o = reinterpret_cast<float4*>(x) + (row_off ? (int64_t)row_off[b] + t : (int64_t)row) * C4;
     const float4* e = reinterpret_cast<const float4*>(emb) + (ok ? id : 0) * C4;
     for (int c = threadIdx.x; c < C4; c += blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -419,9 +420,9 @@ __global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __res
     }
 }
 void launch_embed(hipStream_t s, const int64_t* ids, const float* emb, int vocab, int B, int L, int C, const int* len,
-                  float* x) {
+                  float* x, const int* row_off) {
     if (B * L == 0) return;
-    STN_KLAUNCH(embed_kernel, dim3(B * L), dim3(64), 0, s, ids, emb, vocab, L, C, len, x);
+    STN_KLAUNCH(embed_kernel, dim3(B * L), dim3(64), 0, s, ids, emb, vocab, L, C, len, x, row_off);
 }
 
 __global__ void mask_to_len_kernel(const float* __restrict__ mask, int L, int* __restrict__ len) {
@@ -667,18 +668,20 @@ void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, in
 
 template <typename InT>
 __global__ void masked_mean_kernel(const InT* __restrict__ x, int L, int C, const int* __restrict__ len,
-                                   float* __restrict__ pooled) {
+                                   float* __restrict__ pooled, const int* __restrict__ row_off) {
     const int b = blockIdx.x, n = len[b];
+    const int64_t r0 = row_off ? (int64_t)row_off[b] : (int64_t)b * L;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (int t = 0; t < n; ++t) s += load1(x + ((int64_t)b * L + t) * C + c);
+        for (int t = 0; t < n; ++t) s += load1(x + (r0 + t) * C + c);
         pooled[(int64_t)b * C + c] = s / (float)(n > 0 ? n : 1);
     }
 }
-void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled) {
+void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled,
+                        const int* row_off) {
     if (B == 0) return;
-    if (in_dtype == BF16) STN_KLAUNCH(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled);
-    else STN_KLAUNCH(masked_mean_kernel<float>, dim3(B), dim3(128), 0, s, static_cast<const float*>(x), L, C, len, pooled);
+    if (in_dtype == BF16) STN_KLAUNCH(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled, row_off);
+    else STN_KLAUNCH(masked_mean_kernel<float>, dim3(B), dim3(128), 0, s, static_cast<const float*>(x), L, C, len, pooled, row_off);
 }
 
 __global__ void softplus_kernel(float* x, int n) {
