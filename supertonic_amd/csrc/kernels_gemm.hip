@@ -5,15 +5,17 @@
 // Used for every dense linear / pointwise conv of the four graphs that replace the reference's
 // Ort::Session::Run sites (/root/reference/cpp/helper.cpp:519,552,643,668).
 //
-// Tiling (wave64, 4 waves = 2x2, each wave a 64x64 output sub-tile = 2x2 MFMA 32x32 tiles):
-//   block tile 128 x 128, K-step = 128 bytes of K per row (64 bf16 / 32 f32)
-//   LDS: 2 stages x (A 16 KiB + W 16 KiB) = 64 KiB  -> 2 workgroups per CU
-//   global -> registers (16-B loads, issued before the MFMAs of the current stage) -> LDS (after them):
-//   one barrier per K-step.
-//   bf16: v_mfma_f32_32x32x16_bf16, fragments by ds_read_b128 from an XOR-swizzled image
-//         (16-B slot = chunk ^ ((row >> 1) & 7): conflict-free for the b128 16-lane groups)
-//   f32 : v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), fragments by ds_read_b32 from a
-//         word-swizzled image (word = k ^ (row & 31): conflict-free per 32-lane half)
+// Three generations live here; launch_gemm picks by shape:
+//   gemm_tiled_kernel<MODE,BM,BN,WM,WN,NSTAGE,KS,ESZ>  (the product path; K % 32 == 0, vector epilogues)
+//       operands HBM/L2 -> LDS by buffer_load ... lds (1 KiB per wave-instruction) into an NSTAGE-deep ring, counted
+//       s_waitcnt vmcnt + raw s_barrier per K-step, ds_read_b128 fragments from an XOR-swizzled image,
+//       v_mfma_f32_32x32x16_bf16 (bf16) or the exact v_mfma_f32_32x32x2_f32 (fp32).  Tile configurations and what each is for:
+//       launch_tiled_auto.  Epilogues: (a) bf16 store through a wave-private transposed LDS image (ds_read_b64_tr_b16),
+//       (b) fp32 slab transpose through the dead ring with 16-byte stores — bias, GELU/SiLU, layer-scale + residual,
+//       row mask or packed-row sequence lookup, per-sequence time vector.
+//   gemm_bf16_ring_kernel   128x128, K % 32 == 0 but epilogue operands not 16-byte aligned (rare).
+//   gemm_bf16_kernel / gemm_f32_kernel   128x128, register-staged double buffer: any K % 8 (bf16) / % 4 (fp32), and the
+//       transposing epilogues (EPI_STORE_T, EPI_EULER_T) of the host-pointer stages.
 // Workgroup -> tile map is XCD-aware: the tiles that share an A row-panel are consecutive and land on
 // one XCD (private 4 MiB L2), the bijective remap of the CDNA4 guide.
 #include "kernels.hpp"
