@@ -29,6 +29,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="utterances per GPU")
     ap.add_argument("--words", type=int, default=10)
+    ap.add_argument("--mixed", action="store_true",
+                    help="config C4 instead of C3: mixed-length utterances (4..48 words), length-sorted and dealt round-robin")
     ap.add_argument("--total-step", type=int, default=5)
     ap.add_argument("--speed", type=float, default=1.05)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -66,7 +68,10 @@ def main():
 
     # ---- workload: 128*N utterances, sorted by length and dealt round-robin ---------------------
     arch = default_arch()
-    texts_all = workload.utterances(args.batch * world, args.words, seed=1234)
+    if args.mixed:
+        texts_all = workload.utterances(args.batch * world, min_words=4, max_words=48, seed=1234)
+    else:
+        texts_all = workload.utterances(args.batch * world, args.words, seed=1234)
     shards = shard_by_length([len(t) for t in texts_all], world)
     mine = shards[rank]
     texts = [texts_all[i] for i in mine]
@@ -212,8 +217,10 @@ def main():
             "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C3: batch={args.batch} {args.words}-word English utterances per GPU, "
-                                   f"{args.total_step} Euler steps, {args.dtype} (BASELINE.json configs[2])",
+            "config": {"workload": (f"C4: batch={args.batch} mixed-length (4..48 words) English utterances per GPU, "
+                                    f"{args.total_step} Euler steps, {args.dtype} (BASELINE.json configs[3])") if args.mixed else
+                                   (f"C3: batch={args.batch} {args.words}-word English utterances per GPU, "
+                                    f"{args.total_step} Euler steps, {args.dtype} (BASELINE.json configs[2])"),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "total_step": args.total_step,
                        "speed": args.speed, "params": eng.param_count, "text_tokens_max": int(ids.shape[1]),
                        "latent_frames_max": L, "audio_sec_per_step": round(audio_per_step, 2),
