@@ -711,7 +711,7 @@ int Engine::trimmed_rows(int B, int L, std::vector<int>* n_host) const {
     bool any = false;
     for (int i = 0; i < B; ++i) {
         const int l6 = bt_.h_llen[i] * ccf;
-        const bool trim = l6 + 2 * rf <= T - rf;
+        const bool trim = l6 + 2 * rf <= T;
         any = any || trim;
         const int n = trim ? l6 + 2 * rf : T;
         if (n_host) n_host->push_back(n);

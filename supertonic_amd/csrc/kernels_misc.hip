@@ -788,7 +788,7 @@ __global__ void trim_len_kernel(const int* __restrict__ len, int B, int ccf, int
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     const int l6 = len[i] * ccf;
-    const bool trim = l6 + 2 * rf <= T - rf;  // a quiet region and the full edge tail exist
+    const bool trim = l6 + 2 * rf <= T;  // the edge tail's whole receptive field [T - 2rf, T) is zero latent (quiet part may be empty)
     n_out[i] = trim ? l6 + 2 * rf : T;
     valid_out[i] = trim ? l6 + rf : T;
 }

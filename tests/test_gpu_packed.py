@@ -150,3 +150,27 @@ def test_trimmed_dense_vocoder_is_bit_identical():
         np.testing.assert_array_equal(outs[True][0], outs[False][0])
         assert outs[True][1] < outs[False][1]
     eng.set_packed_rows(True)
+
+
+def test_trimmed_dense_vocoder_boundary_paddings():
+    """Paddings right at the trimming threshold: exactly 2 x 57 = 114 frames (no quiet region at all, computed frames meet the
+    cached edge tail), 120 frames (6 quiet frames), and 108 frames (not trimmed): all bit-identical to the dense computation."""
+    a = default_arch()
+    eng = binding.Engine(0, "bf16")
+    eng.load_synthetic(a, 7)
+    # latent lengths 60 (longest), 41 (19 latent = 114 vocoder frames of padding), 40 (120), 42 (108: dense), 10
+    durs = np.array([4.17, 2.85, 2.78, 2.92, 0.69], np.float32)
+    B, Lt = 5, 30
+    ids, mask, sttl, sdp = make_inputs(a, B, Lt, np.array([30, 20, 25, 12, 7]), seed=77)
+    outs = {}
+    for packed in (False, True):
+        eng.set_packed_rows(packed)
+        w, d = eng.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=durs, noise_seed=4)
+        lens = host.latent_geometry(d, a.sample_rate, a.base_chunk_size, a.chunk_compress_factor, a.latent_dim)[2]
+        assert list(lens) == [60, 41, 40, 42, 10], lens
+        outs[packed] = (w, eng.vo_rows)
+    np.testing.assert_array_equal(outs[True][0], outs[False][0])
+    T = 60 * 6
+    assert outs[False][1] == B * T
+    assert outs[True][1] == T + (41 * 6 + 114) + (40 * 6 + 114) + T + (10 * 6 + 114), outs[True][1]
+    eng.set_packed_rows(True)
