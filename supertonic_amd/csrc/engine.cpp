@@ -412,7 +412,15 @@ void Engine::gemm(const char* tag, int dt, const void* A, int lda, const Linear&
         double out_b = (double)M * w.N * (e.mode == EPI_STORE ? (e.out_dtype == BF16 ? 2.0 : 4.0) : (e.mode == EPI_RESID ? 8.0 : 4.0));
         prof_begin(tag, 2.0 * M * (double)w.N * w.K, ((double)M * w.K + (double)w.N * w.K) * esz + out_b);
     }
-    launch_gemm(s_, dt, A, lda, w.w.as(dt), w.K, M, w.N, w.K, e);
+    const int sk = gemm_splitk_factor(dt, M, w.N, w.K, e);
+    if (sk > 1) {
+        const Arena::Mark mk = ar_.mark();
+        float* ws = f32_alloc((int64_t)sk * M * w.N);
+        launch_gemm_splitk(s_, dt, A, lda, w.w.as(dt), w.K, M, w.N, w.K, e, sk, ws);
+        ar_.release(mk);  // stream order: the reduction has been enqueued behind the splits
+    } else {
+        launch_gemm(s_, dt, A, lda, w.w.as(dt), w.K, M, w.N, w.K, e);
+    }
     if (prof_on_) prof_end();
 }
 
@@ -1188,7 +1196,9 @@ void Engine::op_gemm(int dtype, int M, int N, int K, const float* A, const float
         pa = a16; pw = w16;
     }
     Epilogue e; e.mode = EPI_STORE; e.act = act; e.out_dtype = F32; e.out = dO; e.ldo = N; e.bias = dB;
-    launch_gemm(s_, dtype, pa, K, pw, K, M, N, K, e);
+    const int sk = gemm_splitk_factor(dtype, M, N, K, e);  // the same decision the model path takes (Engine::gemm)
+    if (sk > 1) launch_gemm_splitk(s_, dtype, pa, K, pw, K, M, N, K, e, sk, f32_alloc((int64_t)sk * M * N));
+    else launch_gemm(s_, dtype, pa, K, pw, K, M, N, K, e);
     STN_HIP(hipMemcpyAsync(out, dO, (size_t)M * N * 4, hipMemcpyDeviceToHost, s_));
     sync();
 }

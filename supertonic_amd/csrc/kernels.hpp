@@ -68,6 +68,7 @@ struct Epilogue {
     const int* row_b = nullptr;       // packed rows: sequence of row m (replaces m / L for rowvec; len must be null then)
     const float* rowvec = nullptr;    // EPI_RESID: per-sequence vector [B][rv_ld] added to every row of sequence b (time
     int rv_ld = 0;                    //            conditioning): resid = (resid + gamma*(acc+bias) + rowvec[b]) * keep
+    int ksplit = 1;                   // tiled kernels: split-K factor (plain fp32 store of partials; launch_gemm_splitk)
     int tr_epilogue = 0;              // tiled kernels, bf16 store: wave-private transposed-image epilogue (set by the launcher)
     unsigned long long* ts = nullptr; // diagnostics (tiled kernels): 4 shader-clock stamps per workgroup — entry, first
                                       // stage landed, K-loop done, epilogue done (stn_op_gemm_phases)
@@ -76,6 +77,11 @@ struct Epilogue {
 // A: [M][lda] (dtype), W: [N][ldw] (same dtype), K % 8 == 0 (bf16) / K % 4 == 0 (f32), 16-byte aligned rows.
 void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                  const Epilogue& e);
+// Deterministic split-K for tiny-M, long-K GEMMs: gemm_splitk_factor says how many ways to split (1 = don't);
+// launch_gemm_splitk runs the splits into `workspace` ([S][M][N] fp32) and reduces them in split order with epilogue e.
+int gemm_splitk_factor(int dtype, int M, int N, int K, const Epilogue& e);
+void launch_gemm_splitk(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const Epilogue& e,
+                        int S, float* workspace);
 
 // depthwise 'same' conv (taps k, dilation dil, weights TRANSPOSED [k][C]) fused with LayerNorm over C.
 // x fp32 [B*L][C] -> y act [B*L][C].  C % 4 == 0, C <= 1024.

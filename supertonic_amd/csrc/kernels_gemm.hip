@@ -567,7 +567,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    // split-K (e.ksplit > 1): workgroup blockIdx.x = split * ntiles + tile sums its own K range into the fp32 workspace
+    // e.out + split * M * N (plain store); splitk_reduce_kernel adds the splits in a fixed order and applies the real epilogue
+    const int ksp = e.ksplit > 1 ? e.ksplit : 1;
+    const int split = ksp > 1 ? (int)blockIdx.x / ntiles : 0;
+    const int tile = xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
+    if (ksp > 1) e.out = static_cast<float*>(e.out) + (size_t)split * M * N;
     const int m0 = (tile / tiles_n) * BM_, n0 = (tile % tiles_n) * BN_;
     unsigned long long t_in = 0, t_first = 0, t_loop = 0;
     if (e.ts) t_in = __builtin_readcyclecounter();
@@ -611,7 +616,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
             offW[j] = (unsigned)(row * ldw + (((lane % CPR) ^ swz(row)) * EPC)) * (unsigned)ESZ;
         }
     }
-    const int nk = K / KS;
+    const int nk_all = K / KS;
+    const int kt0 = split * (nk_all / ksp), nk = ksp > 1 ? kt0 + nk_all / ksp : nk_all;  // this workgroup's K-steps [kt0, nk)
 
 #define STN_ISSUE(kt)                                                                                               \
     {                                                                                                               \
@@ -641,13 +647,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
 
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st)
-        if (st < nk) STN_ISSUE(st);
+        if (kt0 + st < nk) STN_ISSUE(kt0 + st);
 
     const int lr = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         wait_stage<PER_, NSTAGE - 2>(nk - 1 - kt);
         __builtin_amdgcn_s_barrier();
-        if (e.ts && kt == 0) t_first = __builtin_readcyclecounter();
+        if (e.ts && kt == kt0) t_first = __builtin_readcyclecounter();
         const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
         const unsigned char* sb = sa + BM_ * ROWB;
         if constexpr (ESZ == 2) {
@@ -892,7 +898,9 @@ static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, i
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(gemm_tiled)");
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
-    STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles), dim3(WM * WN * 64), lds, s, A, lda,
+    const int ksp = e.ksplit > 1 ? e.ksplit : 1;
+    if (ksp > 1 && (MODE != EPI_STORE || (K / KS) % ksp != 0)) { fprintf(stderr, "stn: split-K needs a plain store epilogue and K/KS divisible by the split\n"); abort(); }
+    STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles * ksp), dim3(WM * WN * 64), lds, s, A, lda,
                        W, ldw, M, N, K, tiles_n, ntiles, e);
 }
 
@@ -996,6 +1004,71 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
         default: STN_LAUNCH(EPI_STORE_T) break;
     }
 #undef STN_LAUNCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-K reduction: out = epilogue(sum over splits, in split order, of the fp32 partials).  Tiny-M GEMMs with a long K
+// (a single utterance's 49 x 384 x 1536 in exact fp32) otherwise run 48 K-steps on 6 workgroups.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, Epilogue e) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [M][N/4]
+    const int N4 = N >> 2;
+    if (i >= (int64_t)M * N4) return;
+    const int m = (int)(i / N4), n = (int)(i - (int64_t)m * N4) * 4;
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int s2 = 1; s2 < S; ++s2) {
+        const float4 b = reinterpret_cast<const float4*>(part + (size_t)s2 * M * N)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    float keep = 1.f;
+    int bsel = 0;
+    if (e.row_b) bsel = e.row_b[m];
+    else if (e.len || e.rowvec) { bsel = m / e.L; if (e.len && m - bsel * e.L >= e.len[bsel]) keep = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t = v[j] + (e.bias ? e.bias[n + j] : 0.f);
+        if (MODE == EPI_STORE) {
+            v[j] = act_out_f(t, e.act, e.out_dtype == BF16) * keep;
+        } else {
+            const float g = e.gamma ? e.gamma[n + j] : 1.f;
+            const float rv = e.rowvec ? e.rowvec[(size_t)bsel * e.rv_ld + n + j] : 0.f;
+            const size_t o = (size_t)m * e.ldo + n + j;
+            v[j] = e.rowvec ? (e.resid[o] + g * t + rv) * keep : (e.resid[o] + g * t) * keep;
+        }
+    }
+    const size_t o = (size_t)m * e.ldo + n;
+    if (MODE == EPI_RESID) {
+        *reinterpret_cast<float4*>(e.resid + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (e.out_dtype == BF16) {
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.out) + o) = pk;
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int gemm_splitk_factor(int dtype, int M, int N, int K, const Epilogue& e) {
+    // exact-fp32 GEMMs of one or two utterances: few 64x64 tiles, many K-steps of 32
+    if (dtype != F32 || M > 128 || K < 1024 || K % 32 || N % 8 || e.ldo % 4 || e.mode > EPI_RESID) return 1;
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64), nk = K / 32;
+    int sk = 1;
+    for (int c : {8, 6, 4, 3, 2}) if (nk % c == 0 && nk / c >= 4 && tiles * c <= 256) { sk = c; break; }
+    return sk;
+}
+
+void launch_gemm_splitk(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const Epilogue& e,
+                        int S, float* workspace /* [S][M][N] */) {
+    Epilogue ep;  // partial sums: plain fp32 store, no bias, no mask
+    ep.mode = EPI_STORE; ep.out_dtype = F32; ep.out = workspace; ep.ldo = N; ep.ksplit = S;
+    launch_gemm(s, dtype, A, lda, W, ldw, M, N, K, ep);
+    const int64_t n4 = (int64_t)M * (N / 4);
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (e.mode == EPI_RESID) STN_KLAUNCH(splitk_reduce_kernel<EPI_RESID>, grid, dim3(256), 0, s, workspace, S, M, N, e);
+    else STN_KLAUNCH(splitk_reduce_kernel<EPI_STORE>, grid, dim3(256), 0, s, workspace, S, M, N, e);
 }
 
 }  // namespace stn

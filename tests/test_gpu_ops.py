@@ -38,7 +38,9 @@ def gelu(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 144, 384), (49, 384, 144), (1000, 512, 2048), (7, 1, 128),
-                                   (257, 130, 72)])
+                                   (257, 130, 72),
+                                   # tiny M, long K: the deterministic split-K path (8 / 8 / 6 splits)
+                                   (49, 384, 1536), (128, 512, 2048), (64, 256, 1152)])
 def test_gemm_f32(eng, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
