@@ -174,7 +174,9 @@ def main():
             if "rocprof_avg_us" in pmc:
                 roof["rocprof_avg_us"] = round(pmc["rocprof_avg_us"], 2)
                 roof["timing_note"] = ("avg_launch_us: HIP events attached to each launch's dispatch packet on the engine's stream "
-                                       "(hipExtLaunchKernelGGL start/stop = the kernel's own begin/end), live over the timed region; "
+                                       "(hipExtLaunchKernelGGL start/stop = the kernel's own begin/end), live over the timed region, where "
+                                       "its un-instrumented neighbours may overlap its first and last microsecond (a fully instrumented "
+                                       "step, `roofline_other`, serialises every launch and reads ~8 % lower); "
                                        "rocprof_avg_us: the same kernel in the committed rocprofv3 kernel trace")
 
     # ---- the same K steps as hipGraph replays (no event timing possible inside a graph): informational, not `value` --------
