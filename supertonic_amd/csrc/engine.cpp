@@ -613,7 +613,8 @@ float* Engine::ve_time_cond_dev(int rows, const float* total_step, const float* 
 }
 
 void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
-                         const float* total_step, const float* current_step, float* denoised, const float* tb, const Ragged* rg) {
+                         const float* total_step, const float* current_step, float* denoised, const float* tb, const Ragged* rg,
+                         const float* dt) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, D = a.latent_dim * a.chunk_compress_factor, nb = a.ve_main_blocks, H = a.ve_heads;
@@ -671,8 +672,12 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     const LNorm ln = lnorm("ve.out_ln");
     launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
     // Euler update fused into the output projection; dt[b] = 1 / total_step[b]
-    float* dtv = f32_alloc(B);
-    launch_reciprocal(s_, total_step, B, dtv);
+    const float* dtv = dt;
+    if (!dtv) {
+        float* d = f32_alloc(B);
+        launch_reciprocal(s_, total_step, B, d);
+        dtv = d;
+    }
     // output projection on the vector-epilogue GEMM path, then the Euler update fused with the [B*L][D] -> [B][D][L] transpose
     float* vel = f32_alloc(M * D);
     Epilogue eo; eo.mode = EPI_STORE; eo.out_dtype = F32; eo.out = vel; eo.ldo = D;
@@ -1088,8 +1093,8 @@ void Engine::enqueue_after_duration(int total_step) {
     VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen, trgp);
     float* tot_all = f32_alloc((int64_t)total_step * B);
     float* cur_all = f32_alloc((int64_t)total_step * B);
-    launch_fill(s_, tot_all, total_step * B, (float)total_step);
-    for (int st = 0; st < total_step; ++st) launch_fill(s_, cur_all + (size_t)st * B, B, (float)st);
+    float* dt_all = f32_alloc(B);
+    launch_step_counters(s_, tot_all, cur_all, dt_all, B, total_step);
     const float* tb_all = ve_time_cond_dev(total_step * B, tot_all, cur_all);
     const size_t tb_stride = (size_t)B * a.ve_main_blocks * a.ve_dim;
     Ragged rg;
@@ -1106,7 +1111,7 @@ void Engine::enqueue_after_duration(int total_step) {
     int cur = 0;
     for (int st = 0; st < total_step; ++st) {
         ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, tot_all + (size_t)st * B, cur_all + (size_t)st * B, b.xt[cur ^ 1],
-                    tb_all + (size_t)st * tb_stride, rgp);
+                    tb_all + (size_t)st * tb_stride, rgp, dt_all);
         cur ^= 1;
     }
     final_xt_ = cur;

@@ -100,7 +100,7 @@ class Engine {
     struct Ragged { const int* off = nullptr; const int* row_b = nullptr; int rows = 0; };
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                      const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr,
-                     const Ragged* rg = nullptr);
+                     const Ragged* rg = nullptr, const float* dt = nullptr /* 1/total_step per utterance, if precomputed */);
     // vlen (optional, device [B]): valid vocoder frames per utterance — the length-aware mode (see set_vocoder_mode)
     // vrows > 0 (with vlen): run the vocoder on packed rows — vrows = sum of vlen — and unpack into the padded wav at the end
     // valid (with vlen, vrows): the exact trimmed DENSE mode — rows are computed on vlen[b] frames, exact below valid[b], and

@@ -164,6 +164,7 @@ void launch_reciprocal(hipStream_t s, const float* in, int n, float* out);
 void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out);
 // total_step/current_step helper: fill n floats
 void launch_fill(hipStream_t s, float* x, int n, float v);
+void launch_step_counters(hipStream_t s, float* tot /*[steps][B]*/, float* cur /*[steps][B]*/, float* dt /*[B]*/, int B, int steps);
 // waveform epilogue: pcm[i] = int16(clamp(w[i], -1, 1) * 32767)  (truncation, cpp/helper.cpp:986-987)
 // rows x W samples -> int16 PCM rows at pcm + row * dst_stride (dst_stride >= W)
 void launch_f32_to_pcm16(hipStream_t s, const float* w, int64_t rows, int W, int16_t* pcm, int64_t dst_stride);

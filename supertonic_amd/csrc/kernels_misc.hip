@@ -719,6 +719,16 @@ __global__ void fill_kernel(float* x, int n, float v) {
 void launch_fill(hipStream_t s, float* x, int n, float v) {
     if (n) STN_KLAUNCH(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, v);
 }
+// the step counters of a whole Euler loop in one launch: tot[st][b] = steps, cur[st][b] = st, dt[b] = 1 / steps
+__global__ void step_counters_kernel(float* __restrict__ tot, float* __restrict__ cur, float* __restrict__ dt, int B, int steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * steps) { tot[i] = (float)steps; cur[i] = (float)(i / B); }
+    if (i < B) dt[i] = 1.0f / (float)steps;
+}
+void launch_step_counters(hipStream_t s, float* tot, float* cur, float* dt, int B, int steps) {
+    const int n = B * steps;
+    if (n) STN_KLAUNCH(step_counters_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tot, cur, dt, B, steps);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller; element (utt, d, t) depends only on (seed, utt, d, t)
