@@ -33,7 +33,7 @@ def parse():
                     help="config C4 instead of C3: mixed-length utterances (4..48 words), length-sorted and dealt round-robin")
     ap.add_argument("--total-step", type=int, default=5)
     ap.add_argument("--speed", type=float, default=1.05)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=128, help="utterances timed on the CPU oracle (0 = skip); 128 = the whole batch, ~10 s")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     return ap.parse_args()
@@ -159,7 +159,7 @@ def main():
         bytes_per_launch = st["bytes"] / max(st["launches"], 1)
         is_gemm = "gemm" in dominant or "attention" in dominant
         if is_gemm:
-            peak = 2500.0 if args.dtype == "bf16" else 157.3
+            peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4))
         else:
@@ -247,7 +247,7 @@ def main():
             for k, v in top:
                 ms = v["ms"] / max(v["launches"], 1)
                 if "gemm" in k or "attention" in k:
-                    peak = 2500.0 if args.dtype == "bf16" else 157.3
+                    peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
                     a_ = v["flops"] / max(v["launches"], 1) / (ms * 1e-3) / 1e12
                     other[k] = {"bound": "mfma", "achieved": round(a_, 1), "unit": "TFLOP/s", "frac": round(a_ / peak, 4), "avg_us": round(ms * 1e3, 1)}
                 else:
@@ -259,12 +259,12 @@ def main():
             # for a compute-dense stage: the fused-ideal vocoder sits ~6x above the ridge point.
             vo_ms = sum(v["ms"] for k, v in fam_stats.items() if k.startswith("vo."))
             if vo_ms > 0:
-                es = 2 if args.dtype == "bf16" else 4
+                es = 2 if args.dtype in ("bf16", "f16") else 4
                 frames = B * L * arch.chunk_compress_factor
                 bytes_frame = es * arch.latent_dim + arch.vo_blocks * 2 * arch.vo_dim * es + arch.base_chunk_size * 4
                 flops_frame = (arch.vo_blocks * (2 * arch.vo_dim * arch.vo_hidden * 2 + 2 * arch.vo_kernel * arch.vo_dim)
                                + 2 * arch.vo_in_kernel * arch.latent_dim * arch.vo_dim + 2 * arch.vo_dim * arch.base_chunk_size)
-                peak = 2500.0 if args.dtype == "bf16" else 157.3
+                peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
                 gbs = bytes_frame * frames / (vo_ms * 1e-3) / 1e9
                 tfs = flops_frame * frames / (vo_ms * 1e-3) / 1e12
                 out["vocoder_stage"] = {"frames": frames, "ms": round(vo_ms, 3), "bytes_per_frame_fused_ideal": bytes_frame,

@@ -41,6 +41,8 @@ extern "C" {
 
 #define STN_DTYPE_F32 0   /* fp32 operands, exact fp32 MFMA                        */
 #define STN_DTYPE_BF16 1  /* bf16 GEMM operands, fp32 accumulate + fp32 residual   */
+#define STN_DTYPE_F16 2   /* IEEE half GEMM operands / activations (v_mfma_f32_32x32x16_f16), fp32 accumulate + fp32 residual:
+                           * BASELINE config 5 ("fp16 MFMA linears"); 11 significant bits instead of bf16's 8, range 6.5e4 */
 
 typedef struct stn_handle stn_handle;
 

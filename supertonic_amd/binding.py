@@ -11,8 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstn.so")
 _LIB = None
 
-F32, BF16 = 0, 1
-_DTYPES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, F32: F32, BF16: BF16}
+F32, BF16, F16 = 0, 1, 2
+_DTYPES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "f16": F16, "fp16": F16, "float16": F16, "half": F16,
+           F32: F32, BF16: BF16, F16: F16}
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
 

@@ -302,17 +302,17 @@ int stn_profile_get(stn_handle* h, int idx, char* name, size_t cap, double* ms, 
 
 int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A, const float* W, const float* bias, int act, float* out) {
     STN_TRY(h, { need(M > 0 && N > 0 && K > 0 && A && W && out, "stn_op_gemm: bad argument");
-                 need(K % (dtype == STN_DTYPE_BF16 ? 8 : 4) == 0, "stn_op_gemm: K must be a multiple of 8 (bf16) / 4 (f32)");
+                 need(K % (dtype != STN_DTYPE_F32 ? 8 : 4) == 0, "stn_op_gemm: K must be a multiple of 8 (bf16) / 4 (f32)");
                  h->eng->op_gemm(dtype, M, N, K, A, W, bias, act, out); })
 }
 int stn_op_gemm_bench(stn_handle* h, int dtype, int M, int N, int K, int mode, int iters, double* avg_ms) {
     STN_TRY(h, { need(M > 0 && N > 0 && K > 0 && iters > 0 && avg_ms, "stn_op_gemm_bench: bad argument");
-                 need(K % (dtype == STN_DTYPE_BF16 ? 8 : 4) == 0, "K must be a multiple of 8 (bf16) / 4 (f32)");
+                 need(K % (dtype != STN_DTYPE_F32 ? 8 : 4) == 0, "K must be a multiple of 8 (bf16) / 4 (f32)");
                  *avg_ms = h->eng->op_gemm_bench(dtype, M, N, K, mode, iters); })
 }
 int stn_op_gemm_phases(stn_handle* h, int dtype, int M, int N, int K, int mode, double* out6) {
     STN_TRY(h, { need(M > 0 && N > 0 && K > 0 && out6, "stn_op_gemm_phases: bad argument");
-                 need(K % (dtype == STN_DTYPE_BF16 ? 8 : 4) == 0, "K must be a multiple of 8 (bf16) / 4 (f32)");
+                 need(K % (dtype != STN_DTYPE_F32 ? 8 : 4) == 0, "K must be a multiple of 8 (bf16) / 4 (f32)");
                  h->eng->op_gemm_phases(dtype, M, N, K, mode, out6); })
 }
 int stn_op_dwconv_ln(stn_handle* h, int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w,

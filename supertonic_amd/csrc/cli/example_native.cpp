@@ -1,6 +1,6 @@
 // example_native.cpp — command-line driver with the reference's flags (/root/reference/cpp/example_onnx.cpp:35-50):
 //   --onnx-dir --total-step --speed --n-test --voice-style --text --lang --save-dir --batch
-// plus engine flags: --device N, --dtype {fp32,bf16}, --seed S (0 = unseeded noise, like the reference).
+// plus engine flags: --device N, --dtype {fp32,bf16,fp16}, --seed S (0 = unseeded noise, like the reference).
 // Voice styles: paths to voice-style JSON files; when the model assets are absent (synthetic weights) a
 // non-existing path is taken as a voice NAME and mapped to a deterministic synthetic style.
 #include <sys/stat.h>
@@ -52,7 +52,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--save-dir" && more) save_dir = argv[++i];
         else if (a == "--batch") batch = true;
         else if (a == "--device" && more) opts.device = std::atoi(argv[++i]);
-        else if (a == "--dtype" && more) opts.dtype = std::string(argv[++i]) == "fp32" ? STN_DTYPE_F32 : STN_DTYPE_BF16;
+        else if (a == "--dtype" && more) { const std::string d = argv[++i]; opts.dtype = d == "fp32" ? STN_DTYPE_F32 : d == "fp16" ? STN_DTYPE_F16 : STN_DTYPE_BF16; }
         else if (a == "--seed" && more) opts.noise_seed = std::strtoull(argv[++i], nullptr, 10);
     }
     if (voice_style.size() != text.size()) {

@@ -84,13 +84,19 @@ uint16_t f32_to_bf16(float f) {
     std::memcpy(&u, &f, 4);
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // RNE (weights are finite)
 }
+uint16_t f32_to_f16(float f) {  // IEEE binary16, round to nearest even (the compiler's conversion; weights are finite)
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
 }  // namespace
 
 // =================================================================================================
 // Engine: construction / weights
 // =================================================================================================
 Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
-    if (dtype != F32 && dtype != BF16) throw std::runtime_error("dtype must be 0 (fp32) or 1 (bf16)");
+    if (dtype != F32 && dtype != BF16 && dtype != F16) throw std::runtime_error("dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the engine has no CPU fallback");
@@ -206,7 +212,7 @@ void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<s
         STN_HIP(hipMemcpy(t.f32, v.data(), v.size() * 4, hipMemcpyHostToDevice));
         if (want_bf16) {
             std::vector<uint16_t> h(v.size());
-            for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+            for (size_t i = 0; i < v.size(); ++i) h[i] = dt_ == F16 ? f32_to_f16(v[i]) : f32_to_bf16(v[i]);
             STN_HIP(hipMalloc(reinterpret_cast<void**>(&t.bf16), std::max<size_t>(v.size(), 8) * 2));
             owned_.push_back(t.bf16);
             STN_HIP(hipMemcpy(t.bf16, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -407,9 +413,9 @@ std::vector<std::pair<std::string, KernelStat>> Engine::profile_collect() {
 // =================================================================================================
 void Engine::gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e) {
     if (!e.bias) e.bias = w.b;
-    const double esz = dt == BF16 ? 2.0 : 4.0;
+    const double esz = is_half(dt) ? 2.0 : 4.0;
     if (prof_on_) {
-        double out_b = (double)M * w.N * (e.mode == EPI_STORE ? (e.out_dtype == BF16 ? 2.0 : 4.0) : (e.mode == EPI_RESID ? 8.0 : 4.0));
+        double out_b = (double)M * w.N * (e.mode == EPI_STORE ? (is_half(e.out_dtype) ? 2.0 : 4.0) : (e.mode == EPI_RESID ? 8.0 : 4.0));
         prof_begin(tag, 2.0 * M * (double)w.N * w.K, ((double)M * w.K + (double)w.N * w.K) * esz + out_b);
     }
     const int sk = gemm_splitk_factor(dt, M, w.N, w.K, e);
@@ -438,7 +444,7 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     const Arena::Mark mk = ar_.mark();
     void* xn = act_alloc(M * C);
     void* u = act_alloc(M * hid);
-    if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (dt_ == BF16 ? 2.0 : 4.0)));
+    if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (is_half(dt_) ? 2.0 : 4.0)));
     launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, rg ? len : conv_len, rg ? rg->off : nullptr);
     if (prof_on_) prof_end();
     Epilogue e1;
@@ -457,7 +463,7 @@ void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, co
     // qrg: the query rows (and, for self-attention, the key rows too) are packed; a cross-attention context stays dense
     const int64_t Mq = qrg ? (int64_t)qrg->rows : (int64_t)B * Lq, Mk = (int64_t)B * Lk;
     const Arena::Mark mk = ar_.mark();
-    const size_t esz = dt_ == BF16 ? 2 : 4;
+    const size_t esz = is_half(dt_) ? 2 : 4;
     void* xn = act_alloc(Mq * C);
     if (prof_on_) prof_begin("layernorm", (double)Mq * C * 8, (double)Mq * C * (4.0 + esz));
     launch_layernorm(s_, dt_, x, Mq, C, p.ln.g, p.ln.b, a_.ln_eps, xn);
@@ -621,7 +627,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     const int64_t M = rg ? (int64_t)rg->rows : (int64_t)B * L;  // packed: only the frames the utterances own
     const int* rmask = rg ? nullptr : llen;                     // padded rows are re-zeroed by every residual epilogue
     const int* roff = rg ? rg->off : nullptr;
-    const size_t esz = dt_ == BF16 ? 2 : 4;
+    const size_t esz = is_half(dt_) ? 2 : 4;
     const Arena::Mark mk = ar_.mark();
     const int Dp = (D + 63) / 64 * 64;
     void* z = act_alloc(M * Dp);
@@ -700,7 +706,7 @@ void Engine::prepare_vocoder_constants() {
     if (vo_edge_) { (void)hipFree(vo_edge_); vo_edge_ = nullptr; }
     vo_rf_ = 0;
     const stn_arch& a = a_;
-    if (dt_ != BF16 || !dwconv_ln_supports_packed(a.vo_dim, a.vo_kernel) || a.base_chunk_size % 4) return;
+    if (!is_half(dt_) || !dwconv_ln_supports_packed(a.vo_dim, a.vo_kernel) || a.base_chunk_size % 4) return;
     const int rf = vocoder_receptive_field(), ccf = a.chunk_compress_factor, W = a.base_chunk_size;
     const int Lz = (4 * rf + ccf) / ccf + 1, Tz = Lz * ccf, D = a.latent_dim * ccf;
     ar_.reset();
@@ -743,7 +749,7 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
     const stn_arch& a = a_;
     const int C = a.vo_dim, T = L * a.chunk_compress_factor;
     // length-aware mode on packed rows: only the frames the utterances own exist (bf16 path; needs the comb dwconv kernel)
-    const bool packed = vlen && vrows > 0 && dt_ == BF16 && B <= 1024 && dwconv_ln_supports_packed(C, a.vo_kernel);
+    const bool packed = vlen && vrows > 0 && is_half(dt_) && B <= 1024 && dwconv_ln_supports_packed(C, a.vo_kernel);
     if (valid && !packed) throw std::runtime_error("trimmed vocoder needs the packed bf16 path");
     const int64_t M = packed ? (int64_t)vrows : (int64_t)B * T;
     const Arena::Mark mk = ar_.mark();
@@ -755,7 +761,7 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
     }
     const Ragged* rgp = packed ? &rg : nullptr;
     float* x = f32_alloc(M * C);
-    if (dt_ == BF16) {
+    if (is_half(dt_)) {
         // input conv on the MFMA path: im2col (K = ld*k padded to 64) + GEMM; ~10x the direct fp32 VALU kernel
         const int kp = (a.latent_dim * a.vo_in_kernel + 63) / 64 * 64;
         void* cols = act_alloc(M * kp);
@@ -1029,7 +1035,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     key.vrows = trimmed_rows(B, L, nullptr);
     key.trows = tpk ? b.trows : 0;
     last_vo_rows_ = (int64_t)B * L * a.chunk_compress_factor;
-    if (vo_ragged_ && packed_ve_ && dt_ == BF16) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
+    if (vo_ragged_ && packed_ve_ && is_half(dt_)) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
     else if (key.vrows) last_vo_rows_ = key.vrows; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
@@ -1193,11 +1199,11 @@ void Engine::op_gemm(int dtype, int M, int N, int K, const float* A, const float
     float* dO = f32_alloc((size_t)M * N);
     const void* pa = dA;
     const void* pw = dW;
-    if (dtype == BF16) {
+    if (is_half(dtype)) {
         void* a16 = ar_.alloc((size_t)M * K * 2);
         void* w16 = ar_.alloc((size_t)N * K * 2);
-        launch_cast(s_, BF16, dA, (int64_t)M * K, a16);
-        launch_cast(s_, BF16, dW, (int64_t)N * K, w16);
+        launch_cast(s_, dtype, dA, (int64_t)M * K, a16);
+        launch_cast(s_, dtype, dW, (int64_t)N * K, w16);
         pa = a16; pw = w16;
     }
     Epilogue e; e.mode = EPI_STORE; e.act = act; e.out_dtype = F32; e.out = dO; e.ldo = N; e.bias = dB;
@@ -1224,8 +1230,8 @@ void Engine::op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const 
     void* dy = ar_.alloc(n * 4);
     float* dy32 = f32_alloc(n);
     launch_dwconv_ln(s_, dtype, dx, B, L, C, dw, db, k, dil, dg, dbt, 1e-6f, dy, dlen);
-    if (dtype == BF16) launch_bf16_to_f32(s_, static_cast<const uint16_t*>(dy), (int64_t)n, dy32);
-    STN_HIP(hipMemcpyAsync(y, dtype == BF16 ? dy32 : static_cast<float*>(dy), n * 4, hipMemcpyDeviceToHost, s_));
+    if (is_half(dtype)) launch_half_to_f32(s_, dtype, dy, (int64_t)n, dy32);
+    STN_HIP(hipMemcpyAsync(y, is_half(dtype) ? dy32 : static_cast<float*>(dy), n * 4, hipMemcpyDeviceToHost, s_));
     sync();
 }
 
@@ -1241,9 +1247,9 @@ void Engine::op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const
     int* dql = qlen ? up(ar_, s_, qlen, (size_t)B) : nullptr;
     int* dkl = klen ? up(ar_, s_, klen, (size_t)B) : nullptr;
     const void *pq = dq, *pk = dk, *pv = dv;
-    if (dtype == BF16) {
+    if (is_half(dtype)) {
         void* a = ar_.alloc(nq * 2); void* b = ar_.alloc(nk * 2); void* c = ar_.alloc(nk * 2);
-        launch_cast(s_, BF16, dq, (int64_t)nq, a); launch_cast(s_, BF16, dk, (int64_t)nk, b); launch_cast(s_, BF16, dv, (int64_t)nk, c);
+        launch_cast(s_, dtype, dq, (int64_t)nq, a); launch_cast(s_, dtype, dk, (int64_t)nk, b); launch_cast(s_, dtype, dv, (int64_t)nk, c);
         pq = a; pk = b; pv = c;
     }
     void* dO = ar_.alloc(nq * 4);
@@ -1253,15 +1259,15 @@ void Engine::op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const
     if (prerot) rope_mode &= 0xFF;
     if (prerot) launch_rope_rows(s_, dtype, const_cast<void*>(pk), C, B, Lk, dkl, 1, 0, H, dh, rope_mode, rbase, rgam);
     launch_attention(s_, dtype, pq, C, pk, pv, C, dO, C, B, Lq, Lk, H, dh, dql, dkl, rope_mode, rbase, rgam, prerot);
-    if (dtype == BF16) launch_bf16_to_f32(s_, static_cast<const uint16_t*>(dO), (int64_t)nq, dO32);
-    STN_HIP(hipMemcpyAsync(o, dtype == BF16 ? dO32 : static_cast<float*>(dO), nq * 4, hipMemcpyDeviceToHost, s_));
+    if (is_half(dtype)) launch_half_to_f32(s_, dtype, dO, (int64_t)nq, dO32);
+    STN_HIP(hipMemcpyAsync(o, is_half(dtype) ? dO32 : static_cast<float*>(dO), nq * 4, hipMemcpyDeviceToHost, s_));
     sync();
 }
 
 double Engine::op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters) {
     STN_HIP(hipSetDevice(device_));
     ar_.reset();
-    const size_t esz = dtype == BF16 ? 2 : 4;
+    const size_t esz = is_half(dtype) ? 2 : 4;
     float* tmp = f32_alloc((size_t)std::max((size_t)M * K, (size_t)N * K));
     void* A = ar_.alloc((size_t)M * K * esz);
     void* Wt = ar_.alloc((size_t)N * K * esz);
@@ -1299,7 +1305,7 @@ double Engine::op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters
 void Engine::op_gemm_phases(int dtype, int M, int N, int K, int mode, double* out6) {
     STN_HIP(hipSetDevice(device_));
     ar_.reset();
-    const size_t esz = dtype == BF16 ? 2 : 4;
+    const size_t esz = is_half(dtype) ? 2 : 4;
     float* tmp = f32_alloc((size_t)std::max((size_t)M * K, (size_t)N * K));
     void* A = ar_.alloc((size_t)M * K * esz);
     void* Wt = ar_.alloc((size_t)N * K * esz);

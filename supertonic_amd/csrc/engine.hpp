@@ -28,9 +28,9 @@ namespace stn {
 
 struct DevTensor {
     float* f32 = nullptr;      // canonical fp32 copy (layout noted per tensor)
-    uint16_t* bf16 = nullptr;  // bf16 copy for GEMM operands (matrices only)
+    uint16_t* bf16 = nullptr;  // 16-bit copy for GEMM operands (matrices only) in the engine's format: bf16, or IEEE half for F16 engines
     int rows = 0, cols = 0;
-    const void* as(int dt) const { return dt == BF16 ? static_cast<const void*>(bf16) : static_cast<const void*>(f32); }
+    const void* as(int dt) const { return is_half(dt) ? static_cast<const void*>(bf16) : static_cast<const void*>(f32); }
 };
 
 struct Linear { DevTensor w; const float* b = nullptr; int N = 0, K = 0; };
@@ -204,7 +204,7 @@ class Engine {
     void load_weights(const stn_arch& a, const RawSource& src, std::vector<std::string>* names_only);
 
     // building blocks (enqueue on s_)
-    size_t act_bytes(int64_t n) const { return (size_t)n * (dt_ == BF16 ? 2 : 4); }
+    size_t act_bytes(int64_t n) const { return (size_t)n * (is_half(dt_) ? 2 : 4); }
     void* act_alloc(int64_t n) { return ar_.alloc(act_bytes(n)); }
     float* f32_alloc(int64_t n) { return static_cast<float*>(ar_.alloc((size_t)n * 4)); }
     void gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e);

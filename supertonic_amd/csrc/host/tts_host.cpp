@@ -155,7 +155,7 @@ std::unique_ptr<TextToSpeech> loadTextToSpeech(const std::string& onnx_dir, bool
     stn_config cfg{opts.device, opts.dtype};
     stn_handle* h = nullptr;
     if (stn_create(&cfg, &h) != STN_OK) throw std::runtime_error(std::string("engine: ") + stn_last_error(nullptr));
-    std::cout << "Using MI355X (HIP device " << opts.device << ", " << (opts.dtype == STN_DTYPE_BF16 ? "bf16" : "fp32")
+    std::cout << "Using MI355X (HIP device " << opts.device << ", " << (opts.dtype == STN_DTYPE_BF16 ? "bf16" : opts.dtype == STN_DTYPE_F16 ? "fp16" : "fp32")
               << ") for inference" << std::endl;
     try {
         const int rc = stn_load_dir(h, onnx_dir.c_str());

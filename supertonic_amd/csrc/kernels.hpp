@@ -41,7 +41,9 @@ inline void stn_check_hip(hipError_t e, const char* what) {
 }
 
 
-enum DType : int { F32 = 0, BF16 = 1 };
+enum DType : int { F32 = 0, BF16 = 1, F16 = 2 };  // F16: IEEE half operands / activations (v_mfma_f32_32x32x16_f16), fp32 accumulate
+__host__ __device__ inline bool is_half(int dt) { return dt == BF16 || dt == F16; }  // 2-byte storage
+typedef _Float16 f16_t;                                          // storage type of the F16 mode (bf16 is raw uint16_t)
 enum ActFn : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 
 // GEMM epilogue description:  acc[m][n] = sum_k A[m][k] * W[n][k]
@@ -160,8 +162,9 @@ void launch_randn_masked(hipStream_t s, uint64_t seed, const int64_t* utt_ids, i
 void launch_mask_ncl(hipStream_t s, float* x, int B, int D, int L, const int* len);
 // out[i] = 1 / in[i]
 void launch_reciprocal(hipStream_t s, const float* in, int n, float* out);
-// bf16 -> fp32 copy (tests)
+// bf16 / f16 -> fp32 copy (tests)
 void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out);
+void launch_half_to_f32(hipStream_t s, int in_dtype, const void* in, int64_t n, float* out);
 // total_step/current_step helper: fill n floats
 void launch_fill(hipStream_t s, float* x, int n, float v);
 void launch_step_counters(hipStream_t s, float* tot /*[steps][B]*/, float* cur /*[steps][B]*/, float* dt /*[B]*/, int B, int steps);

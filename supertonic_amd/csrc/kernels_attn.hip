@@ -18,6 +18,8 @@ static constexpr int AQ = 32, AK = 64, ADH_MAX = 96;
 
 __device__ __forceinline__ float ld_act(const float* p) { return *p; }
 __device__ __forceinline__ float ld_act(const uint16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }
+__device__ __forceinline__ float ld_act(const f16_t* p) { return (float)*p; }
+__device__ __forceinline__ void st_act(f16_t* p, float v) { *p = (f16_t)v; }
 __device__ __forceinline__ void st_act(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_act(uint16_t* p, float v) {
     // round-to-nearest-even; inputs are finite softmax averages
@@ -168,8 +170,26 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     const unsigned ra = (ua + 0x7FFFu + ((ua >> 16) & 1u)) >> 16, rb = (ub + 0x7FFFu + ((ub >> 16) & 1u)) >> 16;
     return ra | (rb << 16);
 }
+// 16-bit storage format of the MFMA kernel: bf16 (F16 = false) or IEEE half (F16 = true); same layouts, same instruction timing
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+    if constexpr (F16) { const f16x2_t h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
+    else return pack_bf16x2(a, b);
+}
+template <bool F16>
+__device__ __forceinline__ void unpack_h2(unsigned w, float& lo, float& hi) {
+    if constexpr (F16) { const f16x2_t h = __builtin_bit_cast(f16x2_t, w); lo = (float)h[0]; hi = (float)h[1]; }
+    else { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xFFFF0000u); }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16_t mfma_h(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
-template <int DH>
+template <int DH, bool F16>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ q, int ldq,
                                                         const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                         int ldk, uint16_t* __restrict__ o, int ldo, int Lq, int Lk,
@@ -227,8 +247,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                 const float pp = (float)pos * pscale;
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
-                    float a0[2] = {__uint_as_float(w0[e2] << 16), __uint_as_float(w0[e2] & 0xFFFF0000u)};
-                    float a1[2] = {__uint_as_float(w1[e2] << 16), __uint_as_float(w1[e2] & 0xFFFF0000u)};
+                    float a0[2], a1[2];
+                    unpack_h2<F16>(w0[e2], a0[0], a0[1]);
+                    unpack_h2<F16>(w1[e2], a1[0], a1[1]);
                     float y0[2], y1[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -241,8 +262,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                         y0[u] = (a0[u] * cs - a1[u] * sn) * mul;
                         y1[u] = (a1[u] * cs + a0[u] * sn) * mul;
                     }
-                    o0[e2] = pack_bf16x2(y0[0], y0[1]);
-                    o1[e2] = pack_bf16x2(y1[0], y1[1]);
+                    o0[e2] = pack_h2<F16>(y0[0], y0[1]);
+                    o1[e2] = pack_h2<F16>(y1[0], y1[1]);
                 }
             } else {
                 o0 = w0; o1 = w1;
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 #pragma unroll
             for (int ks = 0; ks < DH / 16; ++ks) {
                 const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+                acc = mfma_h<F16>(a, bq[ks], acc);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 #pragma unroll
             for (int ks = 0; ks < DH / 16; ++ks) {
                 const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (kt * 32 + lr) * QS + (ks * 2 + lh) * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+                acc = mfma_h<F16>(a, bq[ks], acc);
             }
             float p[16];
 #pragma unroll
@@ -324,10 +345,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
                 u32x4_t pw;
-                pw[0] = pack_bf16x2(p[8 * sidx + 0], p[8 * sidx + 1]);
-                pw[1] = pack_bf16x2(p[8 * sidx + 2], p[8 * sidx + 3]);
-                pw[2] = pack_bf16x2(p[8 * sidx + 4], p[8 * sidx + 5]);
-                pw[3] = pack_bf16x2(p[8 * sidx + 6], p[8 * sidx + 7]);
+                pw[0] = pack_h2<F16>(p[8 * sidx + 0], p[8 * sidx + 1]);
+                pw[1] = pack_h2<F16>(p[8 * sidx + 2], p[8 * sidx + 3]);
+                pw[2] = pack_h2<F16>(p[8 * sidx + 4], p[8 * sidx + 5]);
+                pw[3] = pack_h2<F16>(p[8 * sidx + 6], p[8 * sidx + 7]);
                 const bf16x8_t ap = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
                 for (int nd = 0; nd < DH / 32; ++nd) {
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                     const uint2 hi = *reinterpret_cast<const uint2*>(base + 16);
                     u32x4_t vw;
                     vw[0] = lo.x; vw[1] = lo.y; vw[2] = hi.x; vw[3] = hi.y;
-                    oacc[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd], 0, 0, 0);
+                    oacc[nd] = mfma_h<F16>(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd]);
                 }
             }
         }
@@ -372,6 +393,14 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
             if (active) pass_pv(c * kc);
         }
     }
+    // Wait states between the last P V MFMA and the first read of its accumulators.  The compiler pads such reads with s_nop
+    // inside a block but not on this loop-exit edge (ROCm 7.2: v_mfma a[0:15] / s_cbranch / 4 scalar ops / v_accvgpr_read a15,
+    // 6 wait states where 11 are required): query rows 27 and 31 of a wave came back without the last key tile's contribution
+    // (fp16 build, contexts of 49-64 keys).  The accumulators are operands of the asm, so every read is ordered behind it;
+    // tools/check_hazards.py (tests/test_isa_cpu.py) walks the shipped code objects for this pattern.
+    if constexpr (DH == 32) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]));
+    else if constexpr (DH == 64) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]), "+a"(oacc[1]));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]));
     if (!active) return;
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = (nk > 0 && lsum > 0.f) ? 1.0f / lsum : 0.f;
@@ -383,22 +412,22 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
         if (gq < qrows) {
             uint16_t* orow = o + (qrow0 + gq) * ldo + h * DH + lr;
 #pragma unroll
-            for (int nd = 0; nd < DH / 32; ++nd) orow[nd * 32] = (uint16_t)pack_bf16x2(oacc[nd][i] * invq, 0.f);
+            for (int nd = 0; nd < DH / 32; ++nd) orow[nd * 32] = (uint16_t)pack_h2<F16>(oacc[nd][i] * invq, 0.f);
         }
     }
 }
 
-template <int DH>
+template <int DH, bool F16>
 static void launch_attn_mfma(hipStream_t s, const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldk,
                              uint16_t* o, int ldo, int B, int Lq, int Lk, int H, int kc, size_t lds, const int* qlen,
                              const int* klen, int rope_mode, float log_base, float gamma, int k_rot, const int* q_off, const int* k_off) {
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
         // 150 KiB dynamic (the launcher's own bound) + the kernel's static table stay inside the CU's 160 KiB
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(attn_mfma)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<DH, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(attn_mfma)");
     }
     const dim3 grid((Lq + 127) / 128, H, B);
-    STN_KLAUNCH(attn_mfma_kernel<DH>, grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, kc, qlen, klen,
+    STN_KLAUNCH((attn_mfma_kernel<DH, F16>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, o, ldo, Lq, Lk, kc, qlen, klen,
                        rope_mode, log_base, gamma, k_rot, q_off, k_off);
 }
 
@@ -408,7 +437,7 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (B == 0 || Lq == 0) return;
     if ((q_off && !qlen) || (k_off && !klen)) { fprintf(stderr, "stn: packed attention needs the lengths of the packed side\n"); abort(); }
     if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
-    if (dtype == BF16 && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
+    if (is_half(dtype) && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
         !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
         // keys go through LDS in chunks of at most 128 (one chunk covers the 50 style tokens and ~100-token texts; longer texts
         // take several), so the MFMA kernel serves every context length at 2 workgroups per CU
@@ -418,9 +447,9 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
         const uint16_t *q16 = static_cast<const uint16_t*>(q), *k16 = static_cast<const uint16_t*>(k), *v16 = static_cast<const uint16_t*>(v);
         uint16_t* o16 = static_cast<uint16_t*>(o);
         const float lb = logf(rope_base);
-        if (dh == 32) launch_attn_mfma<32>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off);
-        else if (dh == 64) launch_attn_mfma<64>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off);
-        else launch_attn_mfma<96>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off);
+        if (dh == 32) { if (dtype == F16) launch_attn_mfma<32, true>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off); else launch_attn_mfma<32, false>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off); }
+        else if (dh == 64) { if (dtype == F16) launch_attn_mfma<64, true>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off); else launch_attn_mfma<64, false>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off); }
+        else { if (dtype == F16) launch_attn_mfma<96, true>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off); else launch_attn_mfma<96, false>(s, q16, ldq, k16, v16, ldk, o16, ldo, B, Lq, Lk, H, kc, need, qlen, klen, rope_mode, lb, rope_gamma, (int)k_rotated, q_off, k_off); }
         return;
     }
     const int ds = dh + 1;
@@ -431,8 +460,13 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (attr_once.need()) {
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f32)");
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn bf16)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f16)");
     }
-    if (dtype == BF16)
+    if (dtype == F16)
+        STN_KLAUNCH(attn_kernel<f16_t>, grid, dim3(256), lds, s, static_cast<const f16_t*>(q), ldq,
+                           static_cast<const f16_t*>(k), static_cast<const f16_t*>(v), ldk, static_cast<f16_t*>(o), ldo,
+                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
+    else if (dtype == BF16)
         STN_KLAUNCH(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
                            static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), ldk, static_cast<uint16_t*>(o), ldo,
                            Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
@@ -475,7 +509,10 @@ void launch_rope_rows(hipStream_t s, int dtype, void* x, int ld, int B, int L, c
     const int64_t n = (int64_t)B * L * groups * H * (dh / 2);
     if (n == 0 || rope_mode < 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (dtype == BF16)
+    if (dtype == F16)
+        STN_KLAUNCH(rope_rows_kernel<f16_t>, grid, dim3(256), 0, s, static_cast<f16_t*>(x), ld, L, len, groups,
+                           group_stride, H, dh, rope_mode, logf(rope_base), rope_gamma, n, row_off);
+    else if (dtype == BF16)
         STN_KLAUNCH(rope_rows_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<uint16_t*>(x), ld, L, len, groups,
                            group_stride, H, dh, rope_mode, logf(rope_base), rope_gamma, n, row_off);
     else

@@ -88,6 +88,19 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     __hip_bfloat16 h = __float2bfloat16(f);
     return *reinterpret_cast<uint16_t*>(&h);
 }
+// 16-bit formats: bf16 (F16 = false) or IEEE half (F16 = true, the STN_DTYPE_F16 mode): same tiles, same LDS images, same
+// MFMA timing (v_mfma_f32_32x32x16_f16); only the conversion and the instruction differ, both resolved at compile time.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ uint16_t cvt16(float f) {
+    if constexpr (F16) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }  // v_cvt_f16_f32, RNE
+    else return f2bf(f);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // XCD-aware bijective remap of a 1-D grid (consecutive logical tiles -> same XCD).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -98,7 +111,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // One lane's share of the epilogue: accumulator tile (mi, ni) element i lives at
 //   row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), col = lane & 31      (32x32 MFMA C/D map)
-template <int MODE>
+template <int MODE, bool F16 = false>
 __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2][2], int m_base, int n_base, int M,
                                              int N, int lane) {
     const int half = lane >> 5, cl = lane & 31;
@@ -136,7 +149,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2]
                 if (MODE == EPI_STORE) {
                     const float r = act_out_f(v, e.act, e.out_dtype == BF16) * keep;
                     const size_t o = (size_t)m * e.ldo + n;
-                    if (e.out_dtype == BF16) reinterpret_cast<uint16_t*>(e.out)[o] = f2bf(r);
+                    if (e.out_dtype != F32) reinterpret_cast<uint16_t*>(e.out)[o] = cvt16<F16>(r);
                     else reinterpret_cast<float*>(e.out)[o] = r;
                 } else if (MODE == EPI_RESID) {
                     const size_t o = (size_t)m * e.ldo + n;
@@ -157,7 +170,7 @@ __device__ __forceinline__ void run_epilogue(const Epilogue& e, f32x16 (&acc)[2]
 // ---------------------------------------------------------------------------------------------
 // bf16 operands, fp32 accumulate
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, int lda,
                                                           const uint16_t* __restrict__ W, int ldw, int M, int N, int K,
                                                           int tiles_n, int ntiles, Epilogue e) {
@@ -234,14 +247,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const uint16_t* __rest
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mfma16<F16>(a[mi], b[ni], acc[mi][ni]);
         }
         if (more) STN_SWRITE((kt + 1) & 1);
         __syncthreads();
     }
 #undef STN_GLOAD
 #undef STN_SWRITE
-    run_epilogue<MODE>(e, acc, m0 + wm * 64, n0 + wn * 64, M, N, lane);
+    run_epilogue<MODE, F16>(e, acc, m0 + wm * 64, n0 + wn * 64, M, N, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,7 +368,7 @@ static constexpr int RK = 32, RSTAGES = 4, RSTAGE_BYTES = (BM + BN) * RK * 2;  /
 
 #define STN_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, bool F16 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* __restrict__ A, int lda,
                                                                const uint16_t* __restrict__ W, int ldw, int M, int N,
                                                                int K, int tiles_n, int ntiles, Epilogue e) {
@@ -432,13 +445,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mfma16<F16>(a[mi], b[ni], acc[mi][ni]);
         }
     }
 #undef STN_ISSUE
 
     if (!VEC || MODE >= EPI_EULER_T) {
-        run_epilogue<MODE>(e, acc, m0 + wm * 64, n0 + wn * 64, M, N, lane);
+        run_epilogue<MODE, F16>(e, acc, m0 + wm * 64, n0 + wn * 64, M, N, lane);
         return;
     }
     // ---- LDS-staged epilogue -------------------------------------------------------------------------
@@ -477,12 +490,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_ring_kernel(const uint16_t* _
         const size_t o = (size_t)m * e.ldo + n;
         if (MODE == EPI_STORE) {
             act8(v, bias, e.act, e.out_dtype == BF16, keep);
-            if (e.out_dtype == BF16) {
+            if (e.out_dtype != F32) {
                 uint4 pk;
-                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                pk.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-                pk.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                pk.x = (unsigned)cvt16<F16>(v[0]) | ((unsigned)cvt16<F16>(v[1]) << 16);
+                pk.y = (unsigned)cvt16<F16>(v[2]) | ((unsigned)cvt16<F16>(v[3]) << 16);
+                pk.z = (unsigned)cvt16<F16>(v[4]) | ((unsigned)cvt16<F16>(v[5]) << 16);
+                pk.w = (unsigned)cvt16<F16>(v[6]) | ((unsigned)cvt16<F16>(v[7]) << 16);
                 *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + o) = pk;
             } else {
                 float* op = reinterpret_cast<float*>(e.out) + o;
@@ -538,7 +551,7 @@ __device__ __forceinline__ void wait_stage(int ahead) {
     wait_vm<0>();
 }
 
-template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ>
+template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __restrict__ Av, int lda,
                                                                    const void* __restrict__ Wv, int ldw, int M, int N, int K,
                                                                    int tiles_n, int ntiles, Epilogue e) {
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mi], b[ks][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = mfma16<F16>(a[ks][mi], b[ks][ni], acc[mi][ni]);
         } else {
             if (kt + NSTAGE - 1 < nk) STN_ISSUE(kt + NSTAGE - 1);
             // fp32: lane (row r, half h) feeds A[r][k = 2*ks + h]; one ds_read_b128 covers the lane's k for two MFMA steps
@@ -719,7 +732,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     // 32x32 subtile (72-byte rows: conflict-free); the hardware transpose read hands each lane 4 consecutive COLUMNS of one
     // row, two of them make the 16-byte global store.  Against the fp32 slab transpose below: 4 LDS writes per subtile and
     // lane instead of 16, half the read bytes, and no workgroup barrier — every wave drains its tiles at its own pace.
-    if (MODE == EPI_STORE && ESZ == 2 && e.out_dtype == BF16 && e.len == nullptr && e.tr_epilogue) {
+    if (MODE == EPI_STORE && ESZ == 2 && e.out_dtype != F32 && e.len == nullptr && e.tr_epilogue) {
         constexpr int TSTR = 72, TIMG = 32 * TSTR;  // bytes per image row / per image
         static_assert(NSTAGE * STAGE >= NW * 2 * TIMG, "transposed images must fit in the ring");
         typedef short v4s_ __attribute__((ext_vector_type(4)));
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
                 for (int i = 0; i < 16; ++i) v[i] = acc[mi][ni][i] + bs;
                 if (e.act == ACT_GELU) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = gelu_bf16_f(v[i]);
+                    for (int i = 0; i < 16; ++i) v[i] = F16 ? gelu_f(v[i]) : gelu_bf16_f(v[i]);  // half keeps 11 bits: erf form
                 } else if (e.act == ACT_SILU) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = v[i] / (1.0f + expf(-v[i]));
@@ -750,8 +763,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 pk;
-                    pk.x = (unsigned)f2bf(v[4 * g]) | ((unsigned)f2bf(v[4 * g + 1]) << 16);
-                    pk.y = (unsigned)f2bf(v[4 * g + 2]) | ((unsigned)f2bf(v[4 * g + 3]) << 16);
+                    pk.x = (unsigned)cvt16<F16>(v[4 * g]) | ((unsigned)cvt16<F16>(v[4 * g + 1]) << 16);
+                    pk.y = (unsigned)cvt16<F16>(v[4 * g + 2]) | ((unsigned)cvt16<F16>(v[4 * g + 3]) << 16);
                     *reinterpret_cast<uint2*>(img + cl_ * TSTR + (8 * g + 4 * hf_) * 2) = pk;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in order per wave; keep the compiler in order too
@@ -849,12 +862,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             if (MODE == EPI_STORE) {
                 act8(v, bias, e.act, to_bf16, keep[it]);
-                if (to_bf16) {
+                if (e.out_dtype != F32) {
                     uint4 pk;
-                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                    pk.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-                    pk.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    pk.x = (unsigned)cvt16<F16>(v[0]) | ((unsigned)cvt16<F16>(v[1]) << 16);
+                    pk.y = (unsigned)cvt16<F16>(v[2]) | ((unsigned)cvt16<F16>(v[3]) << 16);
+                    pk.z = (unsigned)cvt16<F16>(v[4]) | ((unsigned)cvt16<F16>(v[5]) << 16);
+                    pk.w = (unsigned)cvt16<F16>(v[6]) | ((unsigned)cvt16<F16>(v[7]) << 16);
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + off[it]) = pk;
                 } else {
                     float* op = reinterpret_cast<float*>(e.out) + off[it];
@@ -887,20 +900,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
     }
 }
 
-template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ = 2>
+template <int MODE, int BM_, int BN_, int WM, int WN, int NSTAGE, int KS, int ESZ = 2, bool F16 = false>
 static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const Epilogue& e) {
     constexpr int RPP_ = 1024 / (KS * ESZ), NW_ = WM * WN;
     constexpr bool GEN_ = (BM_ / RPP_) % NW_ != 0 || (BN_ / RPP_) % NW_ != 0;
     constexpr size_t lds = (size_t)NSTAGE * (BM_ + BN_) * KS * ESZ + (GEN_ ? (size_t)NW_ * 1024 : 0);  // + padding-slot scratch
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>),
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ, F16>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(gemm_tiled)");
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
     const int ksp = e.ksplit > 1 ? e.ksplit : 1;
     if (ksp > 1 && (MODE != EPI_STORE || (K / KS) % ksp != 0)) { fprintf(stderr, "stn: split-K needs a plain store epilogue and K/KS divisible by the split\n"); abort(); }
-    STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ>), dim3(ntiles * ksp), dim3(WM * WN * 64), lds, s, A, lda,
+    STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ, F16>), dim3(ntiles * ksp), dim3(WM * WN * 64), lds, s, A, lda,
                        W, ldw, M, N, K, tiles_n, ntiles, e);
 }
 
@@ -940,6 +953,17 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
     // (-4 % ve.pw1, -15 % te.pw1), a loss where a co-resident workgroup's K loop competes for the vector-memory path (vo.pw1)
     et.tr_epilogue = g_tr == 2 || (g_tr == 1 && (cfg == 11 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 18));
     const Epilogue& e_ = et;
+    if (dtype == F16) {  // the shapes the heuristic above picks; STN_GEMM_CFG experiments stay bf16-only
+        switch (cfg) {
+            case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32, 2, true>(s, A, lda, W, ldw, M, N, K, e_); return true;
+            case 8: launch_tiled<MODE, 128, 128, 2, 4, 4, 64, 2, true>(s, A, lda, W, ldw, M, N, K, e_); return true;
+            case 11: launch_tiled<MODE, 256, 256, 4, 4, 4, 32, 2, true>(s, A, lda, W, ldw, M, N, K, e_); return true;
+            case 12: launch_tiled<MODE, 64, 64, 2, 2, 4, 64, 2, true>(s, A, lda, W, ldw, M, N, K, e_); return true;
+            case 17: launch_tiled<MODE, 256, 128, 4, 2, 3, 32, 2, true>(s, A, lda, W, ldw, M, N, K, e_); return true;
+            case 18: launch_tiled<MODE, 192, 256, 3, 4, 4, 32, 2, true>(s, A, lda, W, ldw, M, N, K, e_); return true;
+            default: return false;
+        }
+    }
     switch (cfg) {
         case 1: launch_tiled<MODE, 256, 256, 2, 4, 4, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
         case 2: launch_tiled<MODE, 256, 128, 4, 2, 5, 32>(s, A, lda, W, ldw, M, N, K, e_); return true;
@@ -966,7 +990,7 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
 void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                  const Epilogue& e) {
     if (M <= 0 || N <= 0) return;
-    const int kq = dtype == BF16 ? 8 : 4;
+    const int kq = is_half(dtype) ? 8 : 4;
     if (K <= 0 || K % kq || lda % kq || ldw % kq || (reinterpret_cast<uintptr_t>(A) & 15) ||
         (reinterpret_cast<uintptr_t>(W) & 15)) {
         fprintf(stderr, "stn: launch_gemm: operand shape/alignment violates the kernel contract (K=%d lda=%d ldw=%d)\n", K,
@@ -975,7 +999,7 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
     // v2 ring kernel: bf16, K % 32 == 0.  Vectorised epilogue needs 16-B aligned 8-column groups.
-    const bool ring = dtype == BF16 && K % RK == 0;
+    const bool ring = is_half(dtype) && K % RK == 0;
     const void* optr = e.mode == EPI_RESID ? static_cast<const void*>(e.resid) : e.out;
     const bool vec_ok = e.mode <= EPI_RESID && N % 8 == 0 && e.ldo % 8 == 0 && !(reinterpret_cast<uintptr_t>(optr) & 15) &&
                         (!e.bias || !(reinterpret_cast<uintptr_t>(e.bias) & 15)) && (!e.gamma || !(reinterpret_cast<uintptr_t>(e.gamma) & 15));
@@ -984,16 +1008,19 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
         if (e.mode == EPI_STORE && launch_tiled_auto<EPI_STORE>(s, dtype, A, lda, W, ldw, M, N, K, e)) return;
         if (e.mode == EPI_RESID && launch_tiled_auto<EPI_RESID>(s, dtype, A, lda, W, ldw, M, N, K, e)) return;
     }
-#define STN_LAUNCH(MODE)                                                                                         \
+#define STN_LAUNCH_H(MODE, F16_)                                                                                  \
     if (ring && vec)                                                                                             \
-        STN_KLAUNCH((gemm_bf16_ring_kernel<MODE, true>), dim3(ntiles), dim3(NT), 0, s,                    \
+        STN_KLAUNCH((gemm_bf16_ring_kernel<MODE, true, F16_>), dim3(ntiles), dim3(NT), 0, s,                    \
                            static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e); \
     else if (ring)                                                                                               \
-        STN_KLAUNCH((gemm_bf16_ring_kernel<MODE, false>), dim3(ntiles), dim3(NT), 0, s,                   \
+        STN_KLAUNCH((gemm_bf16_ring_kernel<MODE, false, F16_>), dim3(ntiles), dim3(NT), 0, s,                   \
                            static_cast<const uint16_t*>(A), lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e); \
-    else if (dtype == BF16)                                                                                      \
-        STN_KLAUNCH(gemm_bf16_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const uint16_t*>(A), \
-                           lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e);              \
+    else                                                                                                         \
+        STN_KLAUNCH((gemm_bf16_kernel<MODE, F16_>), dim3(ntiles), dim3(NT), 0, s, static_cast<const uint16_t*>(A), \
+                           lda, static_cast<const uint16_t*>(W), ldw, M, N, K, tiles_n, ntiles, e);
+#define STN_LAUNCH(MODE)                                                                                         \
+    if (dtype == F16) { STN_LAUNCH_H(MODE, true) }                                                               \
+    else if (dtype == BF16) { STN_LAUNCH_H(MODE, false) }                                                        \
     else                                                                                                         \
         STN_KLAUNCH(gemm_f32_kernel<MODE>, dim3(ntiles), dim3(NT), 0, s, static_cast<const float*>(A),     \
                            lda, static_cast<const float*>(W), ldw, M, N, K, tiles_n, ntiles, e);
@@ -1004,6 +1031,7 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
         default: STN_LAUNCH(EPI_STORE_T) break;
     }
 #undef STN_LAUNCH
+#undef STN_LAUNCH_H
 }
 
 // ---------------------------------------------------------------------------------------------

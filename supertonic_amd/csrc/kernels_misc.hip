@@ -30,10 +30,17 @@ __device__ __forceinline__ void store4(uint16_t* p, float a, float b, float c, f
     u.y = (unsigned)f2bf_(c) | ((unsigned)f2bf_(d) << 16);
     *reinterpret_cast<uint2*>(p) = u;
 }
+__device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
+    typedef _Float16 h4_ __attribute__((ext_vector_type(4)));
+    h4_ h = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};  // v_cvt_f16_f32: round to nearest even
+    *reinterpret_cast<h4_*>(p) = h;
+}
 __device__ __forceinline__ void store1(float* p, float a) { *p = a; }
 __device__ __forceinline__ void store1(uint16_t* p, float a) { *p = f2bf_(a); }
+__device__ __forceinline__ void store1(f16_t* p, float a) { *p = (f16_t)a; }
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const uint16_t* p) { return bf2f_(*p); }
+__device__ __forceinline__ float load1(const f16_t* p) { return (float)*p; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -374,13 +381,18 @@ void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L
     if (M == 0) return;
     if (row_off && (!seqlen || !dwconv_ln_supports_packed(C, k))) { fprintf(stderr, "stn: packed dwconv_ln needs lengths, C <= 512, k in {5,7}\n"); abort(); }
     if (out_dtype == BF16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen, row_off)
+        : out_dtype == F16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<f16_t*>(y), seqlen, row_off)
                           : launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen, row_off))
         return;
     if (out_dtype == BF16 ? launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen)
+        : out_dtype == F16 ? launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<f16_t*>(y), seqlen)
                           : launch_dwconv_ln_v2(s, x, M, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen))
         return;
     const dim3 grid((unsigned)((M + 3) / 4));
-    if (out_dtype == BF16)
+    if (out_dtype == F16)
+        STN_KLAUNCH((dwconv_ln_kernel<f16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
+                           ln_b, eps, static_cast<f16_t*>(y), seqlen);
+    else if (out_dtype == BF16)
         STN_KLAUNCH((dwconv_ln_kernel<uint16_t, true>), grid, dim3(256), 0, s, x, M, L, C, w_t, bias, k, dil, ln_g,
                            ln_b, eps, static_cast<uint16_t*>(y), seqlen);
     else
@@ -393,7 +405,10 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
     check_ln_shape(C);
     if (M == 0) return;
     const dim3 grid((unsigned)((M + 3) / 4));
-    if (out_dtype == BF16)
+    if (out_dtype == F16)
+        STN_KLAUNCH((dwconv_ln_kernel<f16_t, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g,
+                           b, eps, static_cast<f16_t*>(y), static_cast<const int*>(nullptr));
+    else if (out_dtype == BF16)
         STN_KLAUNCH((dwconv_ln_kernel<uint16_t, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g,
                            b, eps, static_cast<uint16_t*>(y), static_cast<const int*>(nullptr));
     else
@@ -459,7 +474,8 @@ void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, in
     const int64_t n = (int64_t)B * ldo * L;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) STN_KLAUNCH(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out), len, row_off);
+    if (out_dtype == F16) STN_KLAUNCH(ncl_to_rows_kernel<f16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<f16_t*>(out), len, row_off);
+    else if (out_dtype == BF16) STN_KLAUNCH(ncl_to_rows_kernel<uint16_t>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<uint16_t*>(out), len, row_off);
     else STN_KLAUNCH(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out), len, row_off);
 }
 
@@ -546,7 +562,8 @@ __global__ void cast_kernel(const float* __restrict__ in, int64_t n, OutT* __res
 void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out) {
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) STN_KLAUNCH(cast_kernel<uint16_t>, grid, dim3(256), 0, s, in, n, static_cast<uint16_t*>(out));
+    if (out_dtype == F16) STN_KLAUNCH(cast_kernel<f16_t>, grid, dim3(256), 0, s, in, n, static_cast<f16_t*>(out));
+    else if (out_dtype == BF16) STN_KLAUNCH(cast_kernel<uint16_t>, grid, dim3(256), 0, s, in, n, static_cast<uint16_t*>(out));
     else STN_KLAUNCH(cast_kernel<float>, grid, dim3(256), 0, s, in, n, static_cast<float*>(out));
 }
 
@@ -662,7 +679,8 @@ void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, in
     const int64_t n = (int64_t)B * L * ccf * kp;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (out_dtype == BF16) STN_KLAUNCH(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen, row_off);
+    if (out_dtype == F16) STN_KLAUNCH(vocoder_im2col_kernel<f16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<f16_t*>(cols), seqlen, row_off);
+    else if (out_dtype == BF16) STN_KLAUNCH(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<uint16_t*>(cols), seqlen, row_off);
     else STN_KLAUNCH(vocoder_im2col_kernel<float>, grid, dim3(256), 0, s, latent, L, ld, ccf, k, kp, n, static_cast<float*>(cols), seqlen, row_off);
 }
 
@@ -680,7 +698,8 @@ __global__ void masked_mean_kernel(const InT* __restrict__ x, int L, int C, cons
 void launch_masked_mean(hipStream_t s, int in_dtype, const void* x, int B, int L, int C, const int* len, float* pooled,
                         const int* row_off) {
     if (B == 0) return;
-    if (in_dtype == BF16) STN_KLAUNCH(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled, row_off);
+    if (in_dtype == F16) STN_KLAUNCH(masked_mean_kernel<f16_t>, dim3(B), dim3(128), 0, s, static_cast<const f16_t*>(x), L, C, len, pooled, row_off);
+    else if (in_dtype == BF16) STN_KLAUNCH(masked_mean_kernel<uint16_t>, dim3(B), dim3(128), 0, s, static_cast<const uint16_t*>(x), L, C, len, pooled, row_off);
     else STN_KLAUNCH(masked_mean_kernel<float>, dim3(B), dim3(128), 0, s, static_cast<const float*>(x), L, C, len, pooled, row_off);
 }
 
@@ -705,13 +724,18 @@ __global__ void reciprocal_kernel(const float* in, int n, float* out) {
 void launch_reciprocal(hipStream_t s, const float* in, int n, float* out) {
     if (n) STN_KLAUNCH(reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, out);
 }
-__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, int64_t n, float* __restrict__ out) {
+template <typename InT>
+__global__ void half_to_f32_kernel(const InT* __restrict__ in, int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = bf2f_(in[i]);
+    if (i < n) out[i] = load1(in + i);
 }
-void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out) {
-    if (n) STN_KLAUNCH(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+void launch_half_to_f32(hipStream_t s, int in_dtype, const void* in, int64_t n, float* out) {
+    if (!n) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (in_dtype == F16) STN_KLAUNCH(half_to_f32_kernel<f16_t>, grid, dim3(256), 0, s, static_cast<const f16_t*>(in), n, out);
+    else STN_KLAUNCH(half_to_f32_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(in), n, out);
 }
+void launch_bf16_to_f32(hipStream_t s, const uint16_t* in, int64_t n, float* out) { launch_half_to_f32(s, BF16, in, n, out); }
 __global__ void fill_kernel(float* x, int n, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = v;

@@ -30,6 +30,13 @@ def eng_bf16():
 
 
 @pytest.fixture(scope="module")
+def eng_f16():
+    e = binding.Engine(0, "f16")
+    e.load_synthetic(default_arch(), 7)
+    return e
+
+
+@pytest.fixture(scope="module")
 def eng_f32():
     e = binding.Engine(0, "f32")
     e.load_synthetic(default_arch(), 7)
@@ -67,7 +74,7 @@ def test_c4_mixed_lengths_ragged_batch(ref, eng_f32, eng_bf16):
             assert np.all(lat[b, :, lens[b]:] == 0) and np.abs(lat[b, :, :lens[b]]).min() >= 0
 
 
-def test_c5_multilingual_steps_sweep(ref, eng_bf16):
+def test_c5_multilingual_steps_sweep(ref, eng_bf16, eng_f16):
     texts = ["Good morning to everyone here.", "안녕하세요 반갑습니다", "¿Cómo estás? Mañana será mejor", "Olá, você está bem? Ação",
              "Ça va très bien, merci à vous"]
     langs = ["en", "ko", "es", "pt", "fr"]
@@ -87,6 +94,11 @@ def test_c5_multilingual_steps_sweep(ref, eng_bf16):
         wav, _ = eng_bf16.synthesize(tid, mask, sttl, sdp, steps, 1.0, noise=nz["x"], duration_override=durs)
         mx, rms = rel_err(wav, ref_wav)
         assert rms < 5e-2 and mx < 3e-1, (steps, mx, rms)  # bf16 error does not blow up with more Euler steps
+        # BASELINE config 5 as written: "fp16 MFMA linears" (STN_DTYPE_F16) — same stack, IEEE-half operands and activations
+        wav16, _ = eng_f16.synthesize(tid, mask, sttl, sdp, steps, 1.0, noise=nz["x"], duration_override=durs)
+        mx16, rms16 = rel_err(wav16, ref_wav)
+        assert np.all(np.isfinite(wav16)) and rms16 < 8e-3 and mx16 < 6e-2, (steps, mx16, rms16)
+        assert rms16 < rms  # three more mantissa bits than bf16 must show
 
 
 def test_c4_full_size_sharding_invariance(eng_bf16):

@@ -68,12 +68,35 @@ def test_gemm_bf16(eng, M, N, K):
     assert rms < 6e-3 and mx < 3e-2, (mx, rms)  # bf16 operand rounding: 2^-9 relative per operand
 
 
+def f16_round(x):
+    return np.ascontiguousarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 144, 384), (49, 384, 144), (1000, 512, 2048), (257, 130, 72),
+                                   (7436, 1536, 384), (600, 384, 1536)])
+def test_gemm_f16(eng, M, N, K):
+    """STN_DTYPE_F16 (BASELINE config 5, "fp16 MFMA linears"): IEEE-half operands, v_mfma_f32_32x32x16_f16, fp32 accumulate."""
+    rng = np.random.default_rng(M * 5 + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    got = eng.op_gemm(A, W, b, dtype="f16")
+    ref_rounded = f16_round(A).astype(np.float64) @ f16_round(W).astype(np.float64).T + b
+    mx, _ = rel_err(got, ref_rounded)
+    assert mx < 2e-5, mx  # same rounded operands, fp32 accumulate
+    mx, rms = rel_err(got, A.astype(np.float64) @ W.astype(np.float64).T + b)
+    assert rms < 8e-4 and mx < 4e-3, (mx, rms)  # half operand rounding: 2^-12 relative per operand, 8x tighter than bf16
+    got = eng.op_gemm(A, W, b, act=binding.ACT_GELU, dtype="f16")
+    mx, _ = rel_err(got, gelu(ref_rounded))
+    assert mx < 2e-5, mx  # fp32 output: the erf form
+
+
 def test_gemm_asymmetric_identity(eng):
     """A = I with an asymmetric W catches a swapped row/col accumulator map."""
     K = 128
     A = np.eye(K, dtype=np.float32)
     W = np.arange(K * K, dtype=np.float32).reshape(K, K) % 251
-    for dt in ("f32", "bf16"):
+    for dt in ("f32", "bf16", "f16"):
         got = eng.op_gemm(A, W, None, dtype=dt)
         assert np.array_equal(got, W.T), dt
 
@@ -100,6 +123,9 @@ def test_dwconv_ln(eng, C, k, dil, B, L):
     got = eng.op_dwconv_ln(x, w, b, g, bt, dil, dtype="bf16")
     # output rounded to bf16 (round-to-nearest-even): |err| <= 2^-8 |ref| elementwise (+ the fp32 noise floor)
     assert np.all(np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-5)
+    got = eng.op_dwconv_ln(x, w, b, g, bt, dil, dtype="f16")
+    # output rounded to IEEE half (round-to-nearest-even): |err| <= 2^-11 |ref| elementwise (+ the fp32 noise floor)
+    assert np.all(np.abs(got - ref) <= 2.0 ** -11 * np.abs(ref) + 2e-5)
 
 
 @pytest.mark.parametrize("dh,H,Lq,Lk,rope", [(32, 2, 7, 11, -1), (64, 4, 70, 70, 0), (96, 4, 49, 62, 1), (48, 2, 33, 130, 1),
@@ -141,6 +167,9 @@ def test_attention(eng, dh, H, Lq, Lk, rope):
     got = eng.op_attention(q, k, v, H, qlen, klen, rope, dtype="bf16")
     mx, rms = rel_err(got, ref)
     assert rms < 1.5e-2 and mx < 8e-2, (mx, rms)  # q,k,v,o rounded to bf16
+    got = eng.op_attention(q, k, v, H, qlen, klen, rope, dtype="f16")
+    mx, rms = rel_err(got, ref)
+    assert rms < 2e-3 and mx < 1e-2, (mx, rms)  # q,k,v,p,o rounded to half: 8x tighter than bf16
     if rope >= 0:
         # keys rotated once by a separate pass (how the vector estimator treats its step-invariant text keys): same result
         got2 = eng.op_attention(q, k, v, H, qlen, klen, rope | 0x100, dtype="f32")
@@ -149,6 +178,9 @@ def test_attention(eng, dh, H, Lq, Lk, rope):
         got2 = eng.op_attention(q, k, v, H, qlen, klen, rope | 0x100, dtype="bf16")
         mx, rms = rel_err(got2, ref)
         assert rms < 1.5e-2 and mx < 8e-2, (mx, rms)
+        got2 = eng.op_attention(q, k, v, H, qlen, klen, rope | 0x100, dtype="f16")
+        mx, rms = rel_err(got2, ref)
+        assert rms < 2e-3 and mx < 1e-2, (mx, rms)
 
 
 def test_randn_matches_oracle_philox(eng):
