@@ -169,6 +169,12 @@ def main():
                     algorithmic_flops_per_launch=flops_per_launch, algorithmic_bytes_per_launch=bytes_per_launch)
         pmc = _pmc_traffic(dominant)
         roof["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
+        mu = _pmc_mfma(dominant)
+        if mu:
+            roof["mfma_util_pmc"] = round(mu["mfma_util"], 4)
+            roof["mfma_util_source"] = ("profiles/r01_j_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of this kernel in a "
+                                        "rocprofv3 --pmc pass of this command (matrix-pipe busy share of the dispatch at the clock the chip held; a lower "
+                                        "bound on dispatches this short)")
         if pmc:
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
             if "rocprof_avg_us" in pmc:
@@ -286,6 +292,17 @@ def _pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from an offline `rocprofv3 --pmc` pass of this same command
     (profiles/pmc_traffic.json, written by tools/pmc_summary.py); None until such a pass exists."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(kernel)
+        except Exception:
+            return None
+    return None
+
+
+def _pmc_mfma(kernel):
+    """Matrix-pipe utilisation of the dominant kernel from the committed PMC pass (tools/pmc_mfma.py); None if absent."""
+    p = os.path.join(ROOT, "profiles", "r01_j_mfma_util.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get(kernel)
