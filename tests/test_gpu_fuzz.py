@@ -1,5 +1,8 @@
 """Randomised differential test: engine vs CPU oracle over random small shapes (batch, text lengths, durations, Euler steps,
-speed, vocoder mode, injected or device noise), tiny architecture, both dtypes.  Seeds are fixed: the sweep is deterministic."""
+speed, vocoder mode, injected or device noise), tiny architecture, all three arithmetic modes.  Seeds are fixed: the sweep is
+deterministic.  STN_FUZZ_CASES=<n> lengthens it (the round-1 soak ran 400 cases per mode)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +15,7 @@ from gpu_util import make_inputs, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype,tol_max,tol_rms", [("f32", 1e-4, 3e-5), ("bf16", 1.5e-1, 4e-2)])
+@pytest.mark.parametrize("dtype,tol_max,tol_rms", [("f32", 1e-4, 3e-5), ("bf16", 1.5e-1, 4e-2), ("f16", 2e-2, 5e-3)])
 def test_random_shapes_against_oracle(dtype, tol_max, tol_rms):
     a = tiny_arch()
     ref = RefModel(a, 7)
@@ -21,7 +24,7 @@ def test_random_shapes_against_oracle(dtype, tol_max, tol_rms):
     rng = np.random.default_rng(20260001)
     cs = a.base_chunk_size * a.chunk_compress_factor
     worst = (0.0, None)
-    for case in range(24):
+    for case in range(int(os.environ.get("STN_FUZZ_CASES", "24"))):
         B = int(rng.integers(1, 6))
         Lt = int(rng.integers(1, 40))
         lens = rng.integers(1, Lt + 1, B)
@@ -50,7 +53,7 @@ def test_random_shapes_against_oracle(dtype, tol_max, tol_rms):
             w, d = eng.synthesize(ids, mask, sttl, sdp, steps, speed, duration_override=durs, noise_seed=1000 + case)
         assert w.shape == rw.shape, (case, w.shape, rw.shape)
         if dtype == "f32" or not use_pred:
-            np.testing.assert_allclose(d, rd, rtol=1e-5 if dtype == "f32" else 3e-2, err_msg=str(case))
+            np.testing.assert_allclose(d, rd, rtol={"f32": 1e-5, "bf16": 3e-2, "f16": 4e-3}[dtype], err_msg=str(case))
         mx, rms = rel_err(w, rw)
         assert np.all(np.isfinite(w)) and mx < tol_max and rms < tol_rms, (case, B, Lt, lens, steps, speed, mx, rms)
         if mx > worst[0]:
