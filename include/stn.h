@@ -108,6 +108,11 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * latent frames each utterance owns (sum of lengths rows), 0 = padded [b*L + t] rows with the padding masked to zero after
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
+/* Cross-attention blocks of the vector estimator: 0 (default) = four launches (LayerNorm, q projection, attention, output
+ * projection + residual), 1 = one fused launch per block (16-bit modes, contexts of <= 128 keys).  Same result up to the
+ * rounding of the 16-bit intermediates (tests/test_gpu_xattn.py); the fused form is the slower one at batch 128 as measured in
+ * round 1 and stays opt-in. */
+int stn_set_fused_xattn(stn_handle* h, int on);
 /* rows the vector estimator worked on in the last stn_batch_run: sum of the latent lengths (packed) or B*L (padded) */
 int64_t stn_batch_ve_rows(const stn_handle* h);
 /* frames the vocoder computed in the last stn_batch_run: B*L*ccf, or fewer when the position-independent part of the padding

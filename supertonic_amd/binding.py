@@ -63,6 +63,7 @@ def load():
     L.stn_set_graph_mode.argtypes = [vp, ci]
     L.stn_set_vocoder_mode.argtypes = [vp, ci]
     L.stn_set_row_layout.argtypes = [vp, ci]
+    L.stn_set_fused_xattn.argtypes = [vp, ci]
     L.stn_batch_ve_rows.argtypes = [vp]
     L.stn_batch_ve_rows.restype = ctypes.c_int64
     L.stn_batch_vo_rows.argtypes = [vp]
@@ -220,6 +221,10 @@ class Engine:
     def set_packed_rows(self, on=True):
         """Vector-estimator row layout in batch_run: packed (default, no work on padding) or padded [b*L + t]."""
         self._ck(self._lib.stn_set_row_layout(self._h, int(bool(on))))
+
+    def set_fused_xattn(self, on=True):
+        """Cross-attention blocks of the vector estimator as one fused launch each (default) or as four launches."""
+        self._ck(self._lib.stn_set_fused_xattn(self._h, int(bool(on))))
 
     @property
     def vo_rows(self):

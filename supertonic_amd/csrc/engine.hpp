@@ -108,6 +108,8 @@ class Engine {
     void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr, int vrows = 0,
                      const int* valid = nullptr);
     int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
+    void prepare_xattn_weights();         // fragment-ordered copies of the estimator's cross-attention Wq / Wo (kernels_xattn.hip)
+    std::unordered_map<const void*, const void*> frag_w_;  // row-major 16-bit matrix -> its fragment-ordered copy
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
@@ -153,6 +155,7 @@ class Engine {
     void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
+    void set_fused_xattn(bool on) { fused_xattn_ = on; }
     int64_t last_ve_rows() const { return last_ve_rows_; }
     int64_t last_vo_rows() const { return last_vo_rows_; }  // frames the vocoder computed in the last batch_run  // rows the estimator worked on in the last batch_run
     bool packed_text_ok(int B) const {
@@ -237,12 +240,14 @@ class Engine {
     std::vector<float> reported_dur_;
     void enqueue_after_duration(int total_step);
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int rows = 0, vrows = 0, trows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
-        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && rows == o.rows && vrows == o.vrows && trows == o.trows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false, xattn = false; int rows = 0, vrows = 0, trows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && xattn == o.xattn && rows == o.rows && vrows == o.vrows && trows == o.trows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
     };
     bool graph_on_ = true;
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
+    bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip): correct but, as
+                                // measured, slower than the four-launch form at batch 128 -> opt-in: STN_XATTN=1
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), bf16 engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }
