@@ -246,6 +246,7 @@ class Engine {
     bool graph_on_ = true;
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
+    bool nt_hints_ = true;
     bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip): correct but, as
                                 // measured, slower than the four-launch form at batch 128 -> opt-in: STN_XATTN=1
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;

@@ -71,6 +71,9 @@ struct Epilogue {
     const float* rowvec = nullptr;    // EPI_RESID: per-sequence vector [B][rv_ld] added to every row of sequence b (time
     int rv_ld = 0;                    //            conditioning): resid = (resid + gamma*(acc+bias) + rowvec[b]) * keep
     int ksplit = 1;                   // tiled kernels: split-K factor (plain fp32 store of partials; launch_gemm_splitk)
+    int nt = 0;                       // tiled kernels: 1 = non-temporal 16-bit output stores, for a stream far larger than the Infinity Cache
+                                      // (the vocoder's 245 MB hidden activation): vo.pw1 185 -> 166 us.  The matching non-temporal A loads in
+                                      // pw2 were measured too and cost +9 % (each A panel is read by two column tiles), so there are none
     int tr_epilogue = 0;              // tiled kernels, bf16 store: wave-private transposed-image epilogue (set by the launcher)
     unsigned long long* ts = nullptr; // diagnostics (tiled kernels): 4 shader-clock stamps per workgroup — entry, first
                                       // stage landed, K-loop done, epilogue done (stn_op_gemm_phases)

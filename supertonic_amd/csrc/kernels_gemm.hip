@@ -868,7 +868,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
                     pk.y = (unsigned)cvt16<F16>(v[2]) | ((unsigned)cvt16<F16>(v[3]) << 16);
                     pk.z = (unsigned)cvt16<F16>(v[4]) | ((unsigned)cvt16<F16>(v[5]) << 16);
                     pk.w = (unsigned)cvt16<F16>(v[6]) | ((unsigned)cvt16<F16>(v[7]) << 16);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + off[it]) = pk;
+                    uint4* po = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.out) + off[it]);
+                    if (e.nt & 1) { const u32x4 pv = {pk.x, pk.y, pk.z, pk.w}; __builtin_nontemporal_store(pv, reinterpret_cast<u32x4*>(po)); }
+                    else *po = pk;
                 } else {
                     float* op = reinterpret_cast<float*>(e.out) + off[it];
                     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
