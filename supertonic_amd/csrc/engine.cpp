@@ -452,10 +452,11 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     if (prof_on_) prof_end();
     Epilogue e1;
     e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
-    // a hidden activation larger than half the 256 MB Infinity Cache is written once: non-temporal stores keep it from evicting
-    // the residual stream and the LayerNorm output (vo.pw1 185 -> 166 us; non-temporal loads in pw2 measured +9 %: not used)
-    const bool big_hidden = nt_hints_ && is_half(dt_) && (double)M * hid * 2.0 > 128e6;
-    if (big_hidden) e1.nt = 1;
+    // a hidden activation larger than half the 256 MB Infinity Cache (the vocoder's: 245 MB per block at C3) is written once:
+    // non-temporal stores keep it from evicting the residual stream and the LayerNorm output (vo.pw1 181 -> 162 us).  Measured
+    // and rejected: non-temporal A loads in pw2 (+9 %: each panel is read by two column tiles); running pw1/pw2 slab by slab
+    // over the rows through a cache-sized hidden buffer (2 / 3 / 4 / 6 slabs: vocoder stage 4.08 -> 4.71 / 5.25 / 4.66 / 5.82 ms)
+    if (nt_hints_ && is_half(dt_) && (double)M * hid * 2.0 > 128e6) e1.nt = 1;
     gemm("gemm_pw1_gelu", dt_, xn, C, p.pw1, (int)M, e1);
     Epilogue e2;
     e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.gamma = p.gamma; e2.len = rg ? nullptr : len; e2.L = L; e2.rowvec = rowvec; e2.rv_ld = rv_ld;
