@@ -172,7 +172,7 @@ def main():
         mu = _pmc_mfma(dominant)
         if mu:
             roof["mfma_util_pmc"] = round(mu["mfma_util"], 4)
-            roof["mfma_util_source"] = ("profiles/r01_j_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of this kernel in a "
+            roof["mfma_util_source"] = ("profiles/mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of this kernel in a "
                                         "rocprofv3 --pmc pass of this command (matrix-pipe busy share of the dispatch at the clock the chip held; a lower "
                                         "bound on dispatches this short)")
         if pmc:
@@ -302,7 +302,7 @@ def _pmc_traffic(kernel):
 
 def _pmc_mfma(kernel):
     """Matrix-pipe utilisation of the dominant kernel from the committed PMC pass (tools/pmc_mfma.py); None if absent."""
-    p = os.path.join(ROOT, "profiles", "r01_j_mfma_util.json")
+    p = os.path.join(ROOT, "profiles", "mfma_util.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get(kernel)

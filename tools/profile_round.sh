@@ -25,8 +25,12 @@ S=$(find "$OUT" -name 'trace_kernel_stats.csv' | head -1)
 cp "$S" "profiles/${TAG}_bench_kernel_stats.csv"
 grep '^{' "$OUT/bench.json" | tail -1 > "profiles/${TAG}_bench.json"
 # dominant families of config C3 (kernel template, grid = workgroups x threads)
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 192, 256, 3, 4, 4, 32, 2>' --grid 179712 || echo "  (no rows matched for this family)"
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw2_resid --kernel-substr 'gemm_tiled_kernel<1, 128, 128, 2, 4, 4, 64, 2>' --grid 90624 || echo "  (no rows matched for this family)"
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 256, 128, 4, 2, 3, 32, 2>' --grid 1916928 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 192, 256, 3, 4, 4, 32, 2, false>' --grid 179712 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw2_resid --kernel-substr 'gemm_tiled_kernel<1, 128, 128, 2, 4, 4, 64, 2, false>' --grid 90624 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 256, 128, 4, 2, 3, 32, 2, false>' --grid 1916928 || echo "  (no rows matched for this family)"
 python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 7, 8>' || echo "  (no rows matched for this family)"
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 5, 4>' --grid 163840 || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 5, 2>' || echo "  (no rows matched for this family)"
+# 4) matrix-pipe utilisation pass (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); summarise on the host with tools/pmc_mfma.py
+cd /tmp
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT" -o pmc_mfma -- python3 "$B" --steps 2 --warmup 1 --cpu-sample 0 --no-profile > /dev/null 2> "$OUT/mfma.err"
+echo "mfma pass done" >&2
