@@ -116,7 +116,7 @@ int stn_set_fused_xattn(stn_handle* h, int on);
 /* rows the vector estimator worked on in the last stn_batch_run: sum of the latent lengths (packed) or B*L (padded) */
 int64_t stn_batch_ve_rows(const stn_handle* h);
 /* frames the vocoder computed in the last stn_batch_run: B*L*ccf, or fewer when the position-independent part of the padding
- * was filled from the model's cached zero-latent response (bit-identical result; bf16 engines, packed row layout) */
+ * was filled from the model's cached zero-latent response (bit-identical result; bf16 and f16 engines, packed row layout) */
 int64_t stn_batch_vo_rows(const stn_handle* h);
 int64_t stn_graph_replays(const stn_handle* h);
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len_per_utt);

@@ -719,7 +719,7 @@ int Engine::vocoder_receptive_field() const {
 
 // The vocoder's response to zero latent is position-independent away from data and edges.  One run on a short all-zero
 // latent yields the two pieces every padded tail is made of: the frame whose whole receptive field is zero latent ("quiet"),
-// and the last rf frames before the end of the tensor ("edge").  bf16 engines only (the packed vocoder path).
+// and the last rf frames before the end of the tensor ("edge").  16-bit engines only (the packed vocoder path).
 void Engine::prepare_xattn_weights() {
     frag_w_.clear();
     const stn_arch& a = a_;

@@ -250,7 +250,7 @@ class Engine {
     bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip): correct but, as
                                 // measured, slower than the four-launch form at batch 128 -> opt-in: STN_XATTN=1
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
-    float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), bf16 engines
+    float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }
     int vo_rf_ = 0;
     int trimmed_rows(int B, int L, std::vector<int>* n_host) const;  // sum of the trimmed extents (0: trimming not applicable)

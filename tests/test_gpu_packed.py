@@ -119,12 +119,13 @@ def test_zero_length_utterance_in_a_packed_batch(dtype):
     eng.set_packed_rows(True)
 
 
-def test_trimmed_dense_vocoder_is_bit_identical():
+@pytest.mark.parametrize("dtype16", ["bf16", "f16"])
+def test_trimmed_dense_vocoder_is_bit_identical(dtype16):
     """Default (reference) vocoder semantics: the padding is decoded as zero latent.  Where that padding is longer than twice the
     receptive field the engine computes only len*6 + 114 frames of the utterance and fills the position-independent rest from
     the model's cached zero-latent response — the returned [B, W] array must equal the dense computation BIT FOR BIT."""
     a = default_arch()
-    eng = binding.Engine(0, "bf16")
+    eng = binding.Engine(0, dtype16)
     eng.load_synthetic(a, 7)
     rng = np.random.default_rng(3)
     for case in range(4):
@@ -152,11 +153,12 @@ def test_trimmed_dense_vocoder_is_bit_identical():
     eng.set_packed_rows(True)
 
 
-def test_trimmed_dense_vocoder_boundary_paddings():
+@pytest.mark.parametrize("dtype16", ["bf16", "f16"])
+def test_trimmed_dense_vocoder_boundary_paddings(dtype16):
     """Paddings right at the trimming threshold: exactly 2 x 57 = 114 frames (no quiet region at all, computed frames meet the
     cached edge tail), 120 frames (6 quiet frames), and 108 frames (not trimmed): all bit-identical to the dense computation."""
     a = default_arch()
-    eng = binding.Engine(0, "bf16")
+    eng = binding.Engine(0, dtype16)
     eng.load_synthetic(a, 7)
     # latent lengths 60 (longest), 41 (19 latent = 114 vocoder frames of padding), 40 (120), 42 (108: dense), 10
     durs = np.array([4.17, 2.85, 2.78, 2.92, 0.69], np.float32)
