@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
                                           (512, 7, 4, 9, 471),    # comb R=4
                                           (512, 7, 2, 70, 470),   # comb R=8
                                           (256, 5, 8, 200, 94)])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_dwconv_ln_ragged_equals_per_sequence(C, k, dil, B, L, dtype):
     eng = binding.Engine(0, "f32")
     rng = np.random.default_rng(C + k + dil + B)
@@ -85,7 +85,7 @@ def test_length_aware_batch_matches_oracle_one_by_one():
     assert differs >= 1
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 3e-2), ("f16", 4e-3)])
 def test_length_aware_batch_matches_batch_of_one_full_arch(dtype, tol):
     a = default_arch()
     eng = binding.Engine(0, dtype)
@@ -131,7 +131,7 @@ def test_mode_switch_invalidates_graph():
     assert not np.array_equal(outs[False], outs[True])
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_graph_replay_survives_shape_changes(dtype):
     """Regression: a captured graph holds raw device pointers.  The batch buffers used to be re-allocated by every upload,
     so after a request of another shape the allocator could hand the SAME xt/wav blocks back with the small buffers
