@@ -17,12 +17,14 @@
 // Contexts longer than one 128-key chunk, other widths and fp32 engines take the unfused path (Engine::ve_step_dev).
 //
 // STATUS (round 1): correct (tests/test_gpu_xattn.py: equal to the four-launch form far inside one 16-bit rounding, both layouts,
-// bf16 and f16) but SLOWER at batch 128: 56 us per block against 43 us for the four launches.  In-kernel stamps (-DXA_STAMPS)
-// of a 32-row workgroup: LayerNorm 24 k cycles, q projection 8 k, q write-back + rotation 7 k, attention 33 k (two rounds of
-// staging 8 k + compute 8 k), output projection + residual 46 k.  With one 4-wave workgroup per CU every phase runs at the
-// latency of a single wave's dependent chain (global round trip, 12 ds_bpermute per LayerNorm row, 48 read-modify-writes), where
-// the four launches spread each phase over ~8 waves per CU.  The engine therefore keeps the four-launch form by default
-// (stn_set_fused_xattn / STN_XATTN=1 select this kernel); see DESIGN.md section 9 for what would have to change.
+// bf16 and f16) but SLOWER at batch 128: 15.5 ms per batch with 64-row tiles (16.2 with 32- or 128-row tiles) against 14.9 ms for
+// the four launches.  In-kernel stamps (-DXA_STAMPS) of a 32-row workgroup after the second pass over the kernel (interleaved
+// LayerNorm reductions, scores kept in registers with P normalised on the lane, residual update through an LDS image): LayerNorm
+// 17 k cycles, q projection 8-15 k, q write-back + rotation 8 k, attention 2 x (staging 9 k + compute 8 k), output projection 18 k,
+// residual 11 k = 105 k cycles.  Two things bound it: every 32-row tile streams both weight matrices (576 KB) through its CU's L1
+// (the four-launch GEMMs read them once per 128 rows), and with 4-8 waves per CU each phase runs at the latency of one wave's
+// dependent chain.  The engine therefore keeps the four-launch form by default (stn_set_fused_xattn / STN_XATTN=1 select this
+// kernel); see DESIGN.md section 9 for what would have to change.
 #include "kernels.hpp"
 
 #include <stdio.h>
@@ -178,35 +180,48 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
                     if (r < nrows && lane + 64 * i < C4) h[j][i] = x4[lane + 64 * i];
                 }
             }
+            // the RP rows' two reductions run interleaved (RP independent butterflies per step instead of RP dependent chains)
+            float sm[RP], vr[RP];
 #pragma unroll
             for (int j = 0; j < RP; ++j) {
-                const int r = wave + 4 * (pass * RP + j);
-                if (r >= nrows) {  // rows of the tile beyond the utterance: zeros (their MFMA rows are never stored)
+                sm[j] = 0.f;
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
-                        if (lane + 64 * i < C4) *reinterpret_cast<uint2*>(XS + r * XSTR + (lane + 64 * i) * 8) = make_uint2(0u, 0u);
-                    continue;
-                }
-                float s = 0.f;
+                for (int i = 0; i < NI; ++i) sm[j] += (h[j][i].x + h[j][i].y) + (h[j][i].z + h[j][i].w);
+            }
 #pragma unroll
-                for (int i = 0; i < NI; ++i) s += (h[j][i].x + h[j][i].y) + (h[j][i].z + h[j][i].w);
-                const float mean = wave_sum(s) / (float)C;
-                float v = 0.f;
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int j = 0; j < RP; ++j) sm[j] += __shfl_xor(sm[j], o, 64);
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                sm[j] = sm[j] / (float)C;  // mean
+                vr[j] = 0.f;
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     if (lane + 64 * i < C4) {
-                        const float dx = h[j][i].x - mean, dy = h[j][i].y - mean, dz = h[j][i].z - mean, dw = h[j][i].w - mean;
-                        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                        const float dx = h[j][i].x - sm[j], dy = h[j][i].y - sm[j], dz = h[j][i].z - sm[j], dw = h[j][i].w - sm[j];
+                        vr[j] += (dx * dx + dy * dy) + (dz * dz + dw * dw);
                     }
-                const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int j = 0; j < RP; ++j) vr[j] += __shfl_xor(vr[j], o, 64);
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const int r = wave + 4 * (pass * RP + j);
+                const bool live = r < nrows;  // rows of the tile beyond the utterance: zeros (their MFMA rows are never stored)
+                const float mean = sm[j], rstd = rsqrtf(vr[j] / (float)C + eps);
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int c4 = lane + 64 * i;
                     if (c4 < C4) {
                         const float4 gg = g4[c4], bb = b4[c4];
-                        uint2 u;
-                        u.x = pack_h2<F16>((h[j][i].x - mean) * rstd * gg.x + bb.x, (h[j][i].y - mean) * rstd * gg.y + bb.y);
-                        u.y = pack_h2<F16>((h[j][i].z - mean) * rstd * gg.z + bb.z, (h[j][i].w - mean) * rstd * gg.w + bb.w);
+                        uint2 u = make_uint2(0u, 0u);
+                        if (live) {
+                            u.x = pack_h2<F16>((h[j][i].x - mean) * rstd * gg.x + bb.x, (h[j][i].y - mean) * rstd * gg.y + bb.y);
+                            u.y = pack_h2<F16>((h[j][i].z - mean) * rstd * gg.z + bb.z, (h[j][i].w - mean) * rstd * gg.w + bb.w);
+                        }
                         *reinterpret_cast<uint2*>(XS + r * XSTR + c4 * 8) = u;
                     }
                 }
@@ -317,76 +332,85 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
 #pragma unroll
             for (int ks = 0; ks < DH / 16; ++ks)
                 bqf[ks] = *reinterpret_cast<const bf16x8_t*>(XS + (qbase + lr) * XSTR + h * DH * 2 + (ks * 2 + lh) * 16);
-            float m = -1e30f, lsum = 0.f;
-            for (int kt = 0; kt < nkt; ++kt) {  // running maximum of the scores (S^T = K Q^T: keys on the accumulator rows)
-                f32x16_t acc;
+            // all scores of the chunk (<= 4 key tiles of 32) stay in registers: one QK^T pass, the row maximum, the exponentials and
+            // their row sum, then P is scaled by 1 / sum ON THE LANE (a lane is a query in this layout) before it becomes the A operand
+            // of P V — the output needs no per-row normalisation (16 ds_bpermute per task in the two-pass form)
+            f32x16_t sc[4];
+            float m = -1e30f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt < nkt) {
 #pragma unroll
-                for (int ks = 0; ks < DH / 16; ++ks) {
-                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Kb + (kt * 32 + lr) * KSTR + (ks * 2 + lh) * 16);
-                    acc = mfma_h<F16>(a, bqf[ks], acc);
-                }
+                    for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                    m = fmaxf(m, key < nk ? acc[i] : -1e30f);
+                    for (int ks = 0; ks < DH / 16; ++ks) {
+                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Kb + (kt * 32 + lr) * KSTR + (ks * 2 + lh) * 16);
+                        sc[kt] = mfma_h<F16>(a, bqf[ks], sc[kt]);
+                    }
                 }
             }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < nkt) {
+                    asm volatile("s_nop 7" : "+v"(sc[kt]));  // (cheap) keeps the reads below behind the MFMAs whatever the block layout
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                        sc[kt][i] = key < nk ? sc[kt][i] : -1e30f;
+                        m = fmaxf(m, sc[kt][i]);
+                    }
+                }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float lsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < nkt) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float pv = sc[kt][i] > -1e29f ? exp2f(sc[kt][i] - m) : 0.f;
+                        sc[kt][i] = pv;
+                        lsum += pv;
+                    }
+                }
+            lsum += __shfl_xor(lsum, 32, 64);
+            const float inv = (nk > 0 && lsum > 0.f) ? 1.0f / lsum : 0.f;
             f32x16_t oacc[DH / 32];
 #pragma unroll
             for (int nd = 0; nd < DH / 32; ++nd)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[nd][i] = 0.f;
-            for (int kt = 0; kt < nkt; ++kt) {  // exp, row sums, P V (QK^T recomputed; P is the A operand with no lane movement)
-                f32x16_t acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < nkt) {
 #pragma unroll
-                for (int ks = 0; ks < DH / 16; ++ks) {
-                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Kb + (kt * 32 + lr) * KSTR + (ks * 2 + lh) * 16);
-                    acc = mfma_h<F16>(a, bqf[ks], acc);
-                }
-                float p[16];
+                    for (int sidx = 0; sidx < 2; ++sidx) {
+                        u32x4_t pw;
+                        pw[0] = pack_h2<F16>(sc[kt][8 * sidx + 0] * inv, sc[kt][8 * sidx + 1] * inv);
+                        pw[1] = pack_h2<F16>(sc[kt][8 * sidx + 2] * inv, sc[kt][8 * sidx + 3] * inv);
+                        pw[2] = pack_h2<F16>(sc[kt][8 * sidx + 4] * inv, sc[kt][8 * sidx + 5] * inv);
+                        pw[3] = pack_h2<F16>(sc[kt][8 * sidx + 6] * inv, sc[kt][8 * sidx + 7] * inv);
+                        const bf16x8_t ap = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                    p[i] = key < nk ? exp2f(acc[i] - m) : 0.f;
-                    lsum += p[i];
-                }
-#pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx) {
-                    u32x4_t pw;
-                    pw[0] = pack_h2<F16>(p[8 * sidx + 0], p[8 * sidx + 1]);
-                    pw[1] = pack_h2<F16>(p[8 * sidx + 2], p[8 * sidx + 3]);
-                    pw[2] = pack_h2<F16>(p[8 * sidx + 4], p[8 * sidx + 5]);
-                    pw[3] = pack_h2<F16>(p[8 * sidx + 6], p[8 * sidx + 7]);
-                    const bf16x8_t ap = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-                    for (int nd = 0; nd < DH / 32; ++nd) {
-                        const unsigned char* base = Vb + (nd * 32 + lr) * VS + (kt * 32 + 16 * sidx + 4 * lh) * 2;
-                        const uint2 lo = *reinterpret_cast<const uint2*>(base);
-                        const uint2 hi = *reinterpret_cast<const uint2*>(base + 16);
-                        u32x4_t vw;
-                        vw[0] = lo.x; vw[1] = lo.y; vw[2] = hi.x; vw[3] = hi.y;
-                        oacc[nd] = mfma_h<F16>(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd]);
+                        for (int nd = 0; nd < DH / 32; ++nd) {
+                            const unsigned char* base = Vb + (nd * 32 + lr) * VS + (kt * 32 + 16 * sidx + 4 * lh) * 2;
+                            const uint2 lo = *reinterpret_cast<const uint2*>(base);
+                            const uint2 hi = *reinterpret_cast<const uint2*>(base + 16);
+                            u32x4_t vw;
+                            vw[0] = lo.x; vw[1] = lo.y; vw[2] = hi.x; vw[3] = hi.y;
+                            oacc[nd] = mfma_h<F16>(ap, __builtin_bit_cast(bf16x8_t, vw), oacc[nd]);
+                        }
                     }
                 }
-            }
-            // wait states between the last MFMA and the first read of its accumulators on the loop-exit edge (see kernels_attn.hip)
+            // wait states between the last MFMA and the first read of its accumulators (see kernels_attn.hip)
             if constexpr (DH == 32) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]));
             else if constexpr (DH == 64) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]), "+a"(oacc[1]));
             else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]));
-            lsum += __shfl_xor(lsum, 32, 64);
-            const float inv = (nk > 0 && lsum > 0.f) ? 1.0f / lsum : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int qrow = (i & 3) + 8 * (i >> 2) + 4 * lh;
-                const float invq = __shfl(inv, qrow, 64);
 #pragma unroll
                 for (int nd = 0; nd < DH / 32; ++nd)  // O_h over Q_h: only this task reads or writes these rows of head h
-                    *reinterpret_cast<uint16_t*>(XS + (qbase + qrow) * XSTR + (h * DH + nd * 32 + lr) * 2) = (uint16_t)pack_h2<F16>(oacc[nd][i] * invq, 0.f);
+                    *reinterpret_cast<uint16_t*>(XS + (qbase + qrow) * XSTR + (h * DH + nd * 32 + lr) * 2) = (uint16_t)pack_h2<F16>(oacc[nd][i], 0.f);
             }
         }
     }
@@ -404,26 +428,40 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
         rows_times_wt<C, MT, NTW, F16>(XS, XSTR, Wo, ncol0, lane, bfr, acc);
         XA_STAMP(14);
-        // residual rows: all loads of one 32-row tile are issued before the first store (the compiler cannot prove that the
-        // stores do not alias the following loads and would otherwise serialise 48 round trips)
+        // residual update through LDS: the accumulators (+ bias) go to an fp32 image [QT][C] over the K / V slots (dead by now), then
+        // every thread adds 16-byte pieces of it to x — 12 independent float4 read-modify-writes per thread and 32-row tile instead of
+        // 48 dependent 4-byte ones per lane
+        float* YS = reinterpret_cast<float*>(Ks);  // [32][C + 4] fp32: one 32-row tile at a time (the launcher sizes the region)
+        constexpr int YSTR = C + 4;  // floats per image row (+4: rows start on different banks)
+        constexpr int C4 = C / 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            float xv[NTW][16];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                    xv[nt][i] = row < nrows ? x[(xrow0 + row) * C + ncol0 + nt * 32 + lr] : 0.f;
-                }
+            if (mt) __syncthreads();  // the previous tile's image has been consumed
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int col = ncol0 + nt * 32 + lr;
                 const float bs = bo ? bo[col] : 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-                    if (row < nrows) x[(xrow0 + row) * C + col] = xv[nt][i] + (acc[mt][nt][i] + bs);
+                for (int i = 0; i < 16; ++i) YS[((i & 3) + 8 * (i >> 2) + 4 * lh) * YSTR + col] = acc[mt][nt][i] + bs;
+            }
+            __syncthreads();
+            for (int idx0 = 0; idx0 < 32 * C4; idx0 += 256 * 4) {
+                float4 xv[4];
+                int rr[4], cc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = idx0 + u * 256 + tid;
+                    rr[u] = idx / C4; cc[u] = idx - rr[u] * C4;
+                    xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < 32 * C4 && mt * 32 + rr[u] < nrows) xv[u] = *reinterpret_cast<const float4*>(x + (xrow0 + mt * 32 + rr[u]) * C + cc[u] * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = idx0 + u * 256 + tid;
+                    if (idx < 32 * C4 && mt * 32 + rr[u] < nrows) {
+                        const float4 yv = *reinterpret_cast<const float4*>(YS + rr[u] * YSTR + cc[u] * 4);
+                        *reinterpret_cast<float4*>(x + (xrow0 + mt * 32 + rr[u]) * C + cc[u] * 4) = make_float4(xv[u].x + yv.x, xv[u].y + yv.y, xv[u].z + yv.z, xv[u].w + yv.w);
+                    }
                 }
             }
         }
@@ -436,7 +474,8 @@ void launch_one(hipStream_t s, float* x, const float* ln_g, const float* ln_b, f
                 const void* vp, int ldk, const void* Wo, const float* bo, int B, int L, int Lk, int kc, const int* qlen, const int* klen,
                 const int* q_off, const int* k_off, int rope_mode, float log_base, float gamma) {
     constexpr int SLOTS = MT <= 2 ? 2 : 1;  // heads staged at a time (see the kernel)
-    const size_t lds = (size_t)MT * 32 * (C * 2 + 16) + SLOTS * ((size_t)kc * (DH * 2 + 16) + (size_t)DH * (kc * 2 + 8));
+    const size_t kv = SLOTS * ((size_t)kc * (DH * 2 + 16) + (size_t)DH * (kc * 2 + 8)), ys = (size_t)32 * (C + 4) * 4;  // K/V slots, later the residual image
+    const size_t lds = (size_t)MT * 32 * (C * 2 + 16) + (kv > ys ? kv : ys);
     static PerDeviceOnce attr_once;
     if (attr_once.need())
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<C, DH, MT, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024),
@@ -472,7 +511,8 @@ void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, c
     const float lb = logf(rope_base);
     // rows per workgroup: the smallest tile that still leaves about two workgroups per CU, so short utterances spread over the chip
     const long t32 = (long)B * ((L + 31) / 32), t64 = (long)B * ((L + 63) / 64);
-    const int mt = t32 <= 768 ? 1 : (t64 <= 768 ? 2 : 4);
+    int mt = t32 <= 256 ? 1 : (t64 <= 768 ? 2 : 4);  // measured at B = 128, L = 78: 64-row tiles 15.5 ms per batch, 32- and 128-row tiles 16.2
+    if (const char* f = getenv("STN_XATTN_MT")) mt = atoi(f) == 4 ? 4 : (atoi(f) == 2 ? 2 : 1);  // experiments
 #define STN_XA(MT_, F16_) launch_one<384, 96, MT_, F16_>(s, x, ln_g, ln_b, eps, Wq, bq, kp, vp, ldk, Wo, bo, B, L, Lk, kc, qlen, klen, q_off, k_off, rope_mode, lb, rope_gamma)
     if (dtype == F16) { if (mt == 1) STN_XA(1, true); else if (mt == 2) STN_XA(2, true); else STN_XA(4, true); }
     else { if (mt == 1) STN_XA(1, false); else if (mt == 2) STN_XA(2, false); else STN_XA(4, false); }
