@@ -138,15 +138,23 @@ int main(int argc, char** argv) {
     hipMemcpy(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     const char* names[] = {"sleep", "mfma", "lds", "valu", "trans"};
-    for (int asm_victim : {1, 8, 9})
-    for (int grid : {2048})
-        for (int mode = 1; mode < 2; ++mode) for (int trial = 0; trial < 3; ++trial) {
-            hipMemset(d_stats, 0, 16);
-            probe<<<grid, 256, 56 * 1024>>>(d_in, nvec, d_stats, mode, reps, -1, 0.1803368801f, 1.f, phases, asm_victim);
-            hipDeviceSynchronize();
-            unsigned st[4]; hipMemcpy(st, d_stats, 16, hipMemcpyDeviceToHost);
-            printf("%s grid %4d neighbour %-5s: mismatching words %u (lanes>=48: %u) in %u workgroups  [%s]\n", (asm_victim == 0 ? "c++" : asm_victim == 1 ? "asm1 as generated" : asm_victim == 2 ? "asm2 nop between pk" : asm_victim == 3 ? "asm3 nop before use" : asm_victim == 4 ? "asm4 pk2 other dst" : asm_victim == 5 ? "asm5 only pk1" : asm_victim == 6 ? "asm6 only pk2" : asm_victim == 7 ? "asm7 nop3 before use" : asm_victim == 8 ? "asm8 pk1 without op_sel" : "asm9 pk_fma with op_sel"), grid, names[mode], st[0], st[1], st[2], hipGetErrorString(hipGetLastError()));
-            fflush(stdout);
-        }
+    auto run = [&](int asm_victim, int grid, int mode) {
+        hipMemset(d_stats, 0, 16);
+        probe<<<grid, 256, 56 * 1024>>>(d_in, nvec, d_stats, mode, reps, -1, 0.1803368801f, 1.f, phases, asm_victim);
+        hipDeviceSynchronize();
+        unsigned st[4]; hipMemcpy(st, d_stats, 16, hipMemcpyDeviceToHost);
+        static const char* vn[] = {"c++ (compiler-generated)", "asm1 as generated", "asm2 nop between pk", "asm3 nop before use", "asm4 pk2 other dst", "asm5 only pk1",
+                                   "asm6 only pk2 (no op_sel)", "asm7 nop3 before use", "asm8 pk1 without op_sel", "asm9 pk_fma with op_sel"};
+        printf("%-26s grid %4d neighbour %-5s: wrong words %5u (in lanes >= 48: %5u) in %4u threads  [%s]\n", vn[asm_victim], grid, names[mode], st[0], st[1], st[2],
+               hipGetErrorString(hipGetLastError()));
+        fflush(stdout);
+    };
+    printf("## 1. which neighbour: the extracted sequence and the compiler-generated staging code, grids of one fill (512) and of four (2048)\n");
+    for (int asm_victim : {1, 0})
+        for (int grid : {512, 2048})
+            for (int mode = 0; mode < 5; ++mode) run(asm_victim, grid, mode);
+    printf("## 2. which instruction (neighbour = MFMA, grid 2048, 3 trials each)\n");
+    for (int asm_victim = 1; asm_victim < 10; ++asm_victim)
+        for (int trial = 0; trial < 3; ++trial) run(asm_victim, 2048, 1);
     return 0;
 }
