@@ -342,8 +342,10 @@ static bool launch_dwconv_ln_v3(hipStream_t s, const float* x, int nseq, int L, 
     // enough wavefronts to fill the chip (256 CUs x ~8): long combs only when there are many frames
     const int64_t M = (int64_t)nseq * L;
     if (M >= 32768) {
+        // k = 7 (the vocoder, 60 k frames at C3): combs of 4 measured 51 us per launch against 57 us for combs of 8 (twice the wavefronts
+        // outweigh 2.5 instead of 1.75 loads per output)
         if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
-        else launch_dwconv_ln_v3_kr<OutT, 7, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+        else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     } else if (M >= 4096) {
         // k = 5 below 16 k frames (the estimator at batch 128: 7.4 k): combs of 2 give twice the wavefronts for 1.5x the loads per output
         // (9.5 -> 8.7 us per launch)

@@ -28,7 +28,7 @@ grep '^{' "$OUT/bench.json" | tail -1 > "profiles/${TAG}_bench.json"
 python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 192, 256, 3, 4, 4, 32, 2, false>' --grid 179712 || echo "  (no rows matched for this family)"
 python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.gemm_pw2_resid --kernel-substr 'gemm_tiled_kernel<1, 128, 128, 2, 4, 4, 64, 2, false>' --grid 90624 || echo "  (no rows matched for this family)"
 python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.gemm_pw1_gelu --kernel-substr 'gemm_tiled_kernel<0, 256, 128, 4, 2, 3, 32, 2, false>' --grid 1916928 || echo "  (no rows matched for this family)"
-python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 7, 8>' || echo "  (no rows matched for this family)"
+python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family vo.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 7, 4>' || echo "  (no rows matched for this family)"
 python3 tools/pmc_summary.py --fetch "$F" --write "$W" --trace "$T" --family ve.dwconv_ln --kernel-substr 'dwconv_ln_v3_kernel<unsigned short, 5, 2>' || echo "  (no rows matched for this family)"
 # 4) matrix-pipe utilisation pass (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); summarise on the host with tools/pmc_mfma.py
 cd /tmp
