@@ -343,7 +343,7 @@ static bool launch_dwconv_ln_v3(hipStream_t s, const float* x, int nseq, int L, 
     const int64_t M = (int64_t)nseq * L;
     if (M >= 32768) {
         // k = 7 (the vocoder, 60 k frames at C3): combs of 4 measured 51 us per launch against 57 us for combs of 8 (twice the wavefronts
-        // outweigh 2.5 instead of 1.75 loads per output)
+        // outweigh 2.5 instead of 1.75 loads per output; combs of 2: 58 us)
         if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 8>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
         else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     } else if (M >= 4096) {
