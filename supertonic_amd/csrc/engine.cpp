@@ -661,7 +661,9 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         }
         const Arena::Mark m2 = ar_.mark();
         void* xn = act_alloc(M * C);
+        if (prof_on_) prof_begin("layernorm", (double)M * C * 8, (double)M * C * (4.0 + esz));
         launch_layernorm(s_, dt_, x, M, C, w.ln.g, w.ln.b, a.ln_eps, xn);
+        if (prof_on_) prof_end();
         void* qb = act_alloc(M * C);
         Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = qb; e.ldo = C;
         gemm("gemm_q", dt_, xn, C, w.q, (int)M, e);
