@@ -6,7 +6,7 @@ from supertonic_amd import binding
 from supertonic_amd.arch import tiny_arch
 
 SHAPES = [  # (name, M, N, K, mode)
-    ("ve.pw1", 9984, 1536, 384, 0), ("ve.pw2", 9984, 384, 1536, 1),
+    ("ve.pw1", 9984, 1536, 384, 0), ("ve.pw2", 9984, 384, 1536, 1), ("ve.pw1.pk", 7436, 1536, 384, 0), ("ve.pw2.pk", 7436, 384, 1536, 1), ("ve.q.pk", 7436, 384, 384, 0),
     ("vo.pw1", 59904, 2048, 512, 0), ("vo.pw2", 59904, 512, 2048, 1),
     ("te.pw1", 12032, 1024, 256, 0), ("te.pw2", 12032, 256, 1024, 1),
     ("ve.q", 9984, 384, 384, 0), ("ve.b1.pw1", 78, 1536, 384, 0), ("ve.b1.pw2", 78, 384, 1536, 1),
