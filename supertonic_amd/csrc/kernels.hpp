@@ -73,7 +73,8 @@ struct Epilogue {
     int ksplit = 1;                   // tiled kernels: split-K factor (plain fp32 store of partials; launch_gemm_splitk)
     int nt = 0;                       // tiled kernels: 1 = non-temporal 16-bit output stores, for a stream far larger than the Infinity Cache
                                       // (the vocoder's 245 MB hidden activation): vo.pw1 185 -> 166 us.  The matching non-temporal A loads in
-                                      // pw2 were measured too and cost +9 % (each A panel is read by two column tiles), so there are none
+                                      // pw2 were measured too and cost +9 % (each A panel is read by two column tiles), non-temporal loads of the old residual in pw2's
+                                      // epilogue +3 %: so there are none
     int tr_epilogue = 0;              // tiled kernels, bf16 store: wave-private transposed-image epilogue (set by the launcher)
     unsigned long long* ts = nullptr; // diagnostics (tiled kernels): 4 shader-clock stamps per workgroup — entry, first
                                       // stage landed, K-loop done, epilogue done (stn_op_gemm_phases)
