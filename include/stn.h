@@ -113,6 +113,12 @@ int stn_set_row_layout(stn_handle* h, int packed);
  * rounding of the 16-bit intermediates (tests/test_gpu_xattn.py); the fused form is the slower one at batch 128 as measured in
  * round 1 and stays opt-in. */
 int stn_set_fused_xattn(stn_handle* h, int on);
+/* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
+ * activation never leaves the registers (bf16 engines, block widths 256 / 384 / 512; other shapes keep the two GEMM launches).
+ * Bit mask over the stages: 1 = vocoder, 2 = vector estimator, 4 = text encoder / duration predictor; 0 = never.  The default
+ * is the set of stages where it measured faster on MI355X.  Same result as the two launches up to fp32
+ * summation order (tests/test_gpu_ffn.py). */
+int stn_set_fused_ffn(stn_handle* h, int stage_mask);
 /* rows the vector estimator worked on in the last stn_batch_run: sum of the latent lengths (packed) or B*L (padded) */
 int64_t stn_batch_ve_rows(const stn_handle* h);
 /* frames the vocoder computed in the last stn_batch_run: B*L*ccf, or fewer when the position-independent part of the padding
@@ -167,6 +173,14 @@ int stn_op_dwconv_ln_ragged(stn_handle* h, int dtype, int B, int L, int C, int k
  * a separate pass first (the way the vector estimator's step-invariant text keys are handled) — same result */
 int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
                      const float* v, const int32_t* qlen_or_null, const int32_t* klen_or_null, int rope_mode, float* o);
+/* the pointwise pair of a ConvNeXt block on host operands (16-bit engines): x <- x + gamma * (W2 . GELU(W1 . xn + b1) + b2)
+ * [+ rowvec[row_b[m]]], W1 [I,C], W2 [C,I], x [M,C] in place.  fused = 1: the K4 kernel, 0: the two tiled GEMM launches. */
+int stn_op_ffn(stn_handle* h, int M, int C, int I, const float* xn /*[M,C]*/, const float* W1, const float* b1, const float* W2,
+               const float* b2_or_null, const float* gamma_or_null, const float* rowvec_or_null /*[nseq,C]*/,
+               const int32_t* row_b_or_null /*[M]*/, int nseq, float* x, int fused);
+/* timing of the same on random device-resident operands.  out5: avg ms per call; fused only: mean shader-clock cycles per
+ * workgroup until the first stage landed / in the tile loop / in the epilogue, and the number of workgroups */
+int stn_op_ffn_bench(stn_handle* h, int M, int C, int I, int fused, int iters, double* out5);
 int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids_or_null,
                  const int32_t* len_or_null, float* out);
 

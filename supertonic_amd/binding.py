@@ -93,6 +93,9 @@ def load():
     L.stn_op_dwconv_ln_ragged.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p]
     L.stn_op_attention.argtypes = [vp, ci, ci, ci, ci, ci, ci, _f32p, _f32p, _f32p, vp, vp, ci, _f32p]
     L.stn_op_randn.argtypes = [vp, cu64, ci, ci, ci, vp, vp, _f32p]
+    L.stn_op_ffn.argtypes = [vp, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, vp, vp, vp, vp, ci, _f32p, ci]
+    L.stn_op_ffn_bench.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    L.stn_set_fused_ffn.argtypes = [vp, ci]
     _LIB = L
     return L
 
@@ -222,6 +225,10 @@ class Engine:
         """Vector-estimator row layout in batch_run: packed (default, no work on padding) or padded [b*L + t]."""
         self._ck(self._lib.stn_set_row_layout(self._h, int(bool(on))))
 
+    def set_fused_ffn(self, mask):
+        """K4 stage mask: 1 vocoder, 2 vector estimator, 4 text encoder / duration predictor (0 = two GEMM launches everywhere)."""
+        self._ck(self._lib.stn_set_fused_ffn(self._h, int(mask)))
+
     def set_fused_xattn(self, on=True):
         """Cross-attention blocks of the vector estimator as one fused launch each (default) or as four launches."""
         self._ck(self._lib.stn_set_fused_xattn(self._h, int(bool(on))))
@@ -332,6 +339,26 @@ class Engine:
         self._ck(self._lib.stn_op_gemm_bench(self._h, self.dtype if dtype is None else _DTYPES[dtype], M, N, K, mode,
                                              iters, ctypes.byref(ms)))
         return ms.value
+
+    def op_ffn(self, xn, W1, b1, W2, b2, gamma, x, rowvec=None, row_b=None, fused=True):
+        """Pointwise pair of a ConvNeXt block (K4): returns x + gamma * (W2 . GELU(W1 . xn + b1) + b2) [+ rowvec[row_b]]."""
+        M, C = xn.shape
+        I = W1.shape[0]
+        out = np.array(x, dtype=np.float32, order="C", copy=True)
+        _, b2p = _opt(b2, np.float32)
+        b2a = _opt(b2, np.float32)[0]
+        ga, gp = _opt(gamma, np.float32)
+        rva, rvp = _opt(rowvec, np.float32)
+        rba, rbp = _opt(row_b, np.int32)
+        b2p = b2a.ctypes.data if b2a is not None else None
+        self._ck(self._lib.stn_op_ffn(self._h, M, C, I, _c(xn, np.float32), _c(W1, np.float32), _c(b1, np.float32), _c(W2, np.float32),
+                                      b2p, gp, rvp, rbp, 0 if rva is None else rva.shape[0], out, int(bool(fused))))
+        return out
+
+    def op_ffn_bench(self, M, C, I, fused=True, iters=20):
+        out = (ctypes.c_double * 5)()
+        self._ck(self._lib.stn_op_ffn_bench(self._h, M, C, I, int(bool(fused)), iters, out))
+        return dict(ms=out[0], first_stage=out[1], tile_loop=out[2], epilogue=out[3], workgroups=int(out[4]))
 
     def op_gemm_phases(self, M, N, K, mode=0, dtype=None):
         out = (ctypes.c_double * 6)()

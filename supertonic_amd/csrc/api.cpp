@@ -248,6 +248,7 @@ int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
 int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_xattn(on != 0); }) }
+int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 7, "stage mask must be in 0..7"); h->eng->set_fused_ffn(mask); }) }
 int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }
 int64_t stn_graph_replays(const stn_handle* h) { return h ? h->eng->graph_replays() : 0; }
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len) {
@@ -334,6 +335,17 @@ int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int
     STN_TRY(h, { need(B > 0 && Lq > 0 && Lk > 0 && H > 0 && dh >= 8 && dh % 8 == 0 && dh <= 96 && q && k && v && o,
                       "stn_op_attention: bad argument");
                  h->eng->op_attention(dtype, B, Lq, Lk, H, dh, q, k, v, qlen, klen, rope_mode, o); })
+}
+int stn_op_ffn(stn_handle* h, int M, int C, int I, const float* xn, const float* W1, const float* b1, const float* W2, const float* b2,
+               const float* gamma, const float* rowvec, const int32_t* row_b, int nseq, float* x, int fused) {
+    STN_TRY(h, { need(M > 0 && C > 0 && I > 0 && C % 8 == 0 && I % 8 == 0 && xn && W1 && b1 && W2 && x, "stn_op_ffn: bad argument");
+                 need(!rowvec || nseq > 0, "stn_op_ffn: rowvec needs nseq > 0");
+                 if (rowvec && row_b) for (int m = 0; m < M; ++m) need(row_b[m] >= 0 && row_b[m] < nseq, "stn_op_ffn: row_b out of range");
+                 h->eng->op_ffn(M, C, I, xn, W1, b1, W2, b2, gamma, rowvec, row_b, nseq, x, fused != 0); })
+}
+int stn_op_ffn_bench(stn_handle* h, int M, int C, int I, int fused, int iters, double* out5) {
+    STN_TRY(h, { need(M > 0 && C > 0 && I > 0 && C % 8 == 0 && I % 8 == 0 && iters > 0 && out5, "stn_op_ffn_bench: bad argument");
+                 h->eng->op_ffn_bench(M, C, I, fused != 0, iters, out5); })
 }
 int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int32_t* len, float* out) {
     STN_TRY(h, { need(B > 0 && D > 0 && L > 0 && out, "stn_op_randn: bad argument"); h->eng->op_randn(seed, B, D, L, utt_ids, len, out); })

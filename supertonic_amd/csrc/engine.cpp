@@ -105,6 +105,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     STN_HIP(hipStreamCreateWithFlags(&own_s_, hipStreamNonBlocking));
     s_ = own_s_;
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
+    if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_XATTN")) fused_xattn_ = atoi(p) != 0;  // A/B switch: one launch per cross-attention block
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
@@ -118,6 +119,8 @@ void Engine::free_weights() {
     for (void* p : owned_) (void)hipFree(p);
     owned_.clear();
     w_.clear();
+    frag_w_.clear();
+    ffn_w_.clear();
     loaded_ = false;
     params_ = 0;
 }
@@ -343,6 +346,7 @@ void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<s
     if (!names_only) {
         loaded_ = true;
         prepare_xattn_weights();
+        prepare_ffn_weights();
         prepare_vocoder_constants();
     }
 }
@@ -446,10 +450,25 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     const int64_t M = rg ? (int64_t)rg->rows : (int64_t)B * L;
     const Arena::Mark mk = ar_.mark();
     void* xn = act_alloc(M * C);
-    void* u = act_alloc(M * hid);
     if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (is_half(dt_) ? 2.0 : 4.0)));
     launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, rg ? len : conv_len, rg ? rg->off : nullptr);
     if (prof_on_) prof_end();
+    // K4: pw1 -> GELU -> pw2 -> layer scale + residual in one launch, the hidden activation never leaves the registers
+    const int stage_bit = stage_[0] == 'v' && stage_[1] == 'o' ? 1 : (stage_[0] == 'v' ? 2 : 4);
+    const auto fw = ffn_w_.find(p.pw1.w.as(dt_));
+    if ((fused_ffn_ & stage_bit) && fw != ffn_w_.end() && ffn_fused_supported(dt_, C, hid) && M * C * 2 < 0x7FFFFFFFll) {
+        FfnArgs fa;
+        fa.xn = xn; fa.ldx = C; fa.w1f = fw->second.w1f; fa.w2f = fw->second.w2f; fa.b1 = p.pw1.b; fa.b2 = p.pw2.b; fa.gamma = p.gamma;
+        fa.x = x; fa.ldo = C; fa.M = (int)M; fa.I = hid; fa.rowvec = rowvec; fa.rv_ld = rv_ld;
+        fa.row_b = (rg && rowvec) ? rg->row_b : nullptr;
+        fa.len = rg ? nullptr : len; fa.L = L;
+        if (prof_on_) prof_begin("ffn_fused", 4.0 * M * (double)C * hid, (double)M * C * (2.0 + 8.0) + 4.0 * C * hid);
+        launch_ffn_fused(s_, dt_, C, fa);
+        if (prof_on_) prof_end();
+        ar_.release(mk);
+        return;
+    }
+    void* u = act_alloc(M * hid);
     Epilogue e1;
     e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
     // a hidden activation larger than half the 256 MB Infinity Cache (the vocoder's: 245 MB per block at C3) is written once:
@@ -738,6 +757,36 @@ void Engine::prepare_xattn_weights() {
                 frag_w_[src] = dst;
             }
         }
+    sync();
+}
+
+// Fragment-ordered copies of the pointwise matrices of every ConvNeXt block the fused kernel supports (kernels_ffn.hip):
+// W1 [I][C] as phase-1 A fragments, W2 [C][I] as phase-2 A fragments in the accumulator-operand k order.
+void Engine::prepare_ffn_weights() {
+    ffn_w_.clear();
+    const stn_arch& a = a_;
+    auto add = [&](const std::string& p, int C, int hid) {
+        if (!ffn_fused_supported(dt_, C, hid)) return;
+        const ConvNeXt c = convnext_w(p);
+        void *w1f = nullptr, *w2f = nullptr;
+        STN_HIP(hipMalloc(&w1f, (size_t)hid * C * 2));
+        owned_.push_back(w1f);
+        STN_HIP(hipMalloc(&w2f, (size_t)hid * C * 2));
+        owned_.push_back(w2f);
+        launch_repack_frag(s_, c.pw1.w.as(dt_), hid, C, w1f);
+        launch_repack_frag_acc(s_, c.pw2.w.as(dt_), C, hid, w2f);
+        ffn_w_[c.pw1.w.as(dt_)] = FfnW{w1f, w2f};
+    };
+    auto S = [](const char* fmt, int i, int j = 0) { char b[64]; snprintf(b, sizeof b, fmt, i, j); return std::string(b); };
+    for (int i = 0; i < a.dp_conv_blocks; ++i) add(S("dp.conv%d", i), a.dp_dim, a.dp_hidden);
+    for (int i = 0; i < a.te_conv_blocks; ++i) add(S("te.conv%d", i), a.te_dim, a.te_hidden);
+    for (int b = 0; b < a.ve_main_blocks; ++b) {
+        for (int j = 0; j < a.ve_dilated; ++j) add(S("ve.m%d.dil%d", b, j), a.ve_dim, a.ve_hidden);
+        add(S("ve.m%d.cn_a", b), a.ve_dim, a.ve_hidden);
+        add(S("ve.m%d.cn_b", b), a.ve_dim, a.ve_hidden);
+    }
+    for (int j = 0; j < a.ve_tail_blocks; ++j) add(S("ve.tail%d", j), a.ve_dim, a.ve_hidden);
+    for (int i = 0; i < a.vo_blocks; ++i) add(S("vo.blk%d", i), a.vo_dim, a.vo_hidden);
     sync();
 }
 
@@ -1387,6 +1436,117 @@ void Engine::op_gemm_phases(int dtype, int M, int N, int K, int mode, double* ou
     if (n == 0) throw std::runtime_error("op_gemm_phases: this shape does not run on the tiled kernel");
     out6[0] = p0 / n; out6[1] = p1 / n; out6[2] = p2 / n;
     out6[3] = (double)(tend - tmin); out6[4] = (double)(tmax_in - tmin); out6[5] = (double)n;
+}
+
+void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma,
+                    const float* rowvec, const int* row_b, int nseq, float* x, bool fused) {
+    STN_HIP(hipSetDevice(device_));
+    if (!is_half(dt_)) throw std::invalid_argument("op_ffn: 16-bit engines only");
+    if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn: shape not supported by the fused kernel");
+    ar_.reset();
+    float* d_xn = up(ar_, s_, xn, (size_t)M * C);
+    float* d_w1 = up(ar_, s_, W1, (size_t)I * C);
+    float* d_w2 = up(ar_, s_, W2, (size_t)C * I);
+    float* d_b1 = up(ar_, s_, b1, (size_t)I);
+    float* d_b2 = b2 ? up(ar_, s_, b2, (size_t)C) : nullptr;
+    float* d_g = gamma ? up(ar_, s_, gamma, (size_t)C) : nullptr;
+    float* d_x = up(ar_, s_, x, (size_t)M * C);
+    float* d_rv = rowvec ? up(ar_, s_, rowvec, (size_t)nseq * C) : nullptr;
+    int* d_rb = (rowvec && row_b) ? up(ar_, s_, row_b, (size_t)M) : nullptr;
+    void* xn16 = act_alloc((int64_t)M * C);
+    void* w1_16 = act_alloc((int64_t)I * C);
+    void* w2_16 = act_alloc((int64_t)I * C);
+    launch_cast(s_, dt_, d_xn, (int64_t)M * C, xn16);
+    launch_cast(s_, dt_, d_w1, (int64_t)I * C, w1_16);
+    launch_cast(s_, dt_, d_w2, (int64_t)I * C, w2_16);
+    if (fused) {
+        void* w1f = act_alloc((int64_t)I * C);
+        void* w2f = act_alloc((int64_t)I * C);
+        launch_repack_frag(s_, w1_16, I, C, w1f);
+        launch_repack_frag_acc(s_, w2_16, C, I, w2f);
+        FfnArgs fa;
+        fa.xn = xn16; fa.ldx = C; fa.w1f = w1f; fa.w2f = w2f; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
+        fa.M = M; fa.I = I; fa.rowvec = d_rv; fa.rv_ld = C; fa.row_b = d_rb; fa.L = M;
+        launch_ffn_fused(s_, dt_, C, fa);
+    } else {
+        void* u = act_alloc((int64_t)M * I);
+        Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
+        launch_gemm(s_, dt_, xn16, C, w1_16, C, M, I, C, e1);
+        Epilogue e2; e2.mode = EPI_RESID; e2.resid = d_x; e2.ldo = C; e2.gamma = d_g; e2.bias = d_b2; e2.rowvec = d_rv; e2.rv_ld = C; e2.row_b = d_rb; e2.L = M;
+        launch_gemm(s_, dt_, u, I, w2_16, I, M, C, I, e2);
+    }
+    STN_HIP(hipGetLastError());
+    STN_HIP(hipMemcpyAsync(x, d_x, sizeof(float) * (size_t)M * C, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::op_ffn_bench(int M, int C, int I, bool fused, int iters, double* out5) {
+    STN_HIP(hipSetDevice(device_));
+    if (!is_half(dt_)) throw std::invalid_argument("op_ffn_bench: 16-bit engines only");
+    if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn_bench: shape not supported by the fused kernel");
+    ar_.reset();
+    for (int i = 0; i < 5; ++i) out5[i] = 0.0;
+    // random operands (the clock a chip holds on zeros is not the clock it holds on data)
+    float* rnd = f32_alloc((int64_t)M * C);
+    launch_randn_masked(s_, 11, nullptr, 1, M, C, nullptr, rnd);
+    float* wr = f32_alloc((int64_t)I * C);
+    launch_randn_masked(s_, 12, nullptr, 1, I, C, nullptr, wr);
+    launch_scale(s_, wr, I * C, 0.05f);
+    void* xn16 = act_alloc((int64_t)M * C);
+    void* w1_16 = act_alloc((int64_t)I * C);
+    void* w2_16 = act_alloc((int64_t)I * C);
+    launch_cast(s_, dt_, rnd, (int64_t)M * C, xn16);
+    launch_cast(s_, dt_, wr, (int64_t)I * C, w1_16);
+    launch_cast(s_, dt_, wr, (int64_t)I * C, w2_16);
+    float* d_b1 = f32_alloc(I);
+    float* d_b2 = f32_alloc(C);
+    float* d_g = f32_alloc(C);
+    launch_fill(s_, d_b1, I, 0.01f); launch_fill(s_, d_b2, C, 0.01f); launch_fill(s_, d_g, C, 0.1f);
+    float* d_x = f32_alloc((int64_t)M * C);
+    STN_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)M * C, s_));
+    void* w1f = act_alloc((int64_t)I * C);
+    void* w2f = act_alloc((int64_t)I * C);
+    launch_repack_frag(s_, w1_16, I, C, w1f);
+    launch_repack_frag_acc(s_, w2_16, C, I, w2f);
+    void* u = fused ? nullptr : act_alloc((int64_t)M * I);
+    const int nwg = (M + 127) / 128;
+    unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
+    auto run = [&](unsigned long long* stamps) {
+        if (fused) {
+            FfnArgs fa;
+            fa.xn = xn16; fa.ldx = C; fa.w1f = w1f; fa.w2f = w2f; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
+            fa.M = M; fa.I = I; fa.L = M; fa.ts = stamps;
+            launch_ffn_fused(s_, dt_, C, fa);
+        } else {
+            Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
+            if (nt_hints_ && (double)M * I * 2.0 > 128e6) e1.nt = 1;
+            launch_gemm(s_, dt_, xn16, C, w1_16, C, M, I, C, e1);
+            Epilogue e2; e2.mode = EPI_RESID; e2.resid = d_x; e2.ldo = C; e2.gamma = d_g; e2.bias = d_b2; e2.L = M;
+            launch_gemm(s_, dt_, u, I, w2_16, I, M, C, I, e2);
+        }
+    };
+    for (int i = 0; i < 3; ++i) run(nullptr);
+    hipEvent_t a, b;
+    STN_HIP(hipEventCreate(&a)); STN_HIP(hipEventCreate(&b));
+    STN_HIP(hipEventRecord(a, s_));
+    for (int i = 0; i < iters; ++i) run(nullptr);
+    STN_HIP(hipEventRecord(b, s_));
+    STN_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    STN_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    out5[0] = ms / iters;
+    if (fused) {
+        run(ts);
+        std::vector<unsigned long long> h((size_t)4 * nwg);
+        STN_HIP(hipMemcpyAsync(h.data(), ts, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s_));
+        sync();
+        double s1 = 0, s2 = 0, s3 = 0;
+        for (int w = 0; w < nwg; ++w) { s1 += (double)(h[4 * w + 1] - h[4 * w]); s2 += (double)(h[4 * w + 2] - h[4 * w + 1]); s3 += (double)(h[4 * w + 3] - h[4 * w + 2]); }
+        out5[1] = s1 / nwg; out5[2] = s2 / nwg; out5[3] = s3 / nwg; out5[4] = nwg;
+    }
+    STN_HIP(hipGetLastError());
+    sync();
 }
 
 void Engine::op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out) {

@@ -111,6 +111,9 @@ class Engine {
     void prepare_xattn_weights();         // fragment-ordered copies of the estimator's cross-attention Wq / Wo (kernels_xattn.hip)
     std::unordered_map<const void*, const void*> frag_w_;  // row-major 16-bit matrix -> its fragment-ordered copy
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
+    void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
+    struct FfnW { const void* w1f = nullptr; const void* w2f = nullptr; };
+    std::unordered_map<const void*, FfnW> ffn_w_;  // key: the block's row-major 16-bit pw1 matrix
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
     void duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur);
@@ -156,6 +159,10 @@ class Engine {
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
     void set_fused_xattn(bool on) { fused_xattn_ = on; }
+    // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
+    // 4 = text encoder / duration predictor.  bf16 engines, widths 256 / 384 / 512 (ffn_fused_supported)
+    void set_fused_ffn(int mask) { fused_ffn_ = mask; }
+    int fused_ffn() const { return fused_ffn_; }
     int64_t last_ve_rows() const { return last_ve_rows_; }
     int64_t last_vo_rows() const { return last_vo_rows_; }  // frames the vocoder computed in the last batch_run  // rows the estimator worked on in the last batch_run
     bool packed_text_ok(int B) const {
@@ -191,6 +198,14 @@ class Engine {
     // epilogue), out[3] = max over workgroups of (end - earliest entry), out[4] = spread of entry times, out[5] = workgroups
     void op_gemm_phases(int dtype, int M, int N, int K, int mode, double* out6);
     void op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out);
+    // K4 on host operands: x <- x + gamma * (W2 . GELU(W1 . xn + b1) + b2) [+ rowvec[row_b[m]]]; xn is rounded to the engine's
+    // 16-bit format first.  fused = false runs the two tiled GEMM launches on the same operands (the pair K4 replaces).
+    void op_ffn(int M, int C, int I, const float* xn, const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma,
+                const float* rowvec /* [nseq][C] or null */, const int* row_b /* host [M] or null */, int nseq, float* x, bool fused);
+    // device-resident timing of the block's pointwise pair on random operands: out[0] = avg ms per call (fused: one launch,
+    // unfused: pw1 + pw2); fused only: out[1..3] = mean cycles per workgroup to the first stage / in the tile loop / in the
+    // epilogue, out[4] = workgroups
+    void op_ffn_bench(int M, int C, int I, bool fused, int iters, double* out5);
 
     Arena& arena() { return ar_; }
 
@@ -247,6 +262,7 @@ class Engine {
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
     bool nt_hints_ = true;
+    int fused_ffn_ = 1;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
     bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip): correct but, as
                                 // measured, slower than the four-launch form at batch 128 -> opt-in: STN_XATTN=1
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;

@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <stdexcept>
+
 namespace stn {
 
 // Kernel-exact timing: when a pair of events is armed here, the NEXT kernel launched through STN_KLAUNCH carries them on
@@ -88,6 +90,29 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
 int gemm_splitk_factor(int dtype, int M, int N, int K, const Epilogue& e);
 void launch_gemm_splitk(hipStream_t s, int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, const Epilogue& e,
                         int S, float* workspace);
+
+// K4 — the pointwise pair of a ConvNeXt block in one launch (kernels_ffn.hip):
+//   x[m][:] <- (x[m][:] + gamma * (W2 . GELU(W1 . xn[m] + b1) + b2) + rowvec[seq(m)]) * keep(m)
+// 16-bit modes; W1 / W2 pre-packed once at model load (launch_repack_frag / launch_repack_frag_acc).
+struct FfnArgs {
+    const void* xn = nullptr; int ldx = 0;        // LayerNorm output [M][ldx], 16-bit activation format
+    const void* w1f = nullptr;                    // W1 [I][C] in MFMA fragment order (launch_repack_frag)
+    const void* w2f = nullptr;                    // W2 [C][I] in accumulator-operand fragment order (launch_repack_frag_acc)
+    const float* b1 = nullptr;                    // [I]
+    const float* b2 = nullptr;                    // [C] or null
+    const float* gamma = nullptr;                 // [C] layer scale or null
+    float* x = nullptr; int ldo = 0;              // residual stream [M][ldo] fp32, updated in place
+    int M = 0, I = 0;
+    const int* row_b = nullptr;                   // packed rows: sequence of row m (for rowvec)
+    const float* rowvec = nullptr; int rv_ld = 0; // per-sequence vector added to every row (time conditioning) or null
+    const int* len = nullptr; int L = 1;          // padded rows: row m = b*L + t is zeroed when t >= len[b] (null: no mask)
+    unsigned long long* ts = nullptr;             // diagnostics: 4 shader-clock stamps per workgroup (entry, first stage, loop, end)
+    int dbg = 0;                                  // diagnostics (STN_FFN_DBG): 1 = every ring hand-over drains vmcnt to 0
+};
+bool ffn_fused_supported(int dtype, int C, int I);
+void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a);
+// W [N][K] row-major 16-bit -> A fragments whose k order matches a GELU'd accumulator used as the B operand (N % 32, K % 32 == 0)
+void launch_repack_frag_acc(hipStream_t s, const void* W, int N, int K, void* Wf);
 
 // depthwise 'same' conv (taps k, dilation dil, weights TRANSPOSED [k][C]) fused with LayerNorm over C.
 // x fp32 [B*L][C] -> y act [B*L][C].  C % 4 == 0, C <= 1024.
