@@ -107,7 +107,6 @@ struct FfnArgs {
     const float* rowvec = nullptr; int rv_ld = 0; // per-sequence vector added to every row (time conditioning) or null
     const int* len = nullptr; int L = 1;          // padded rows: row m = b*L + t is zeroed when t >= len[b] (null: no mask)
     unsigned long long* ts = nullptr;             // diagnostics: 4 shader-clock stamps per workgroup (entry, first stage, loop, end)
-    int dbg = 0;                                  // diagnostics (STN_FFN_DBG): 1 = every ring hand-over drains vmcnt to 0
 };
 bool ffn_fused_supported(int dtype, int C, int I);
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a);

@@ -8,7 +8,7 @@ from supertonic_amd import binding
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 eng = binding.Engine(0, "bf16")
 shapes = [("vo  (C3 dense)", 59904, 512, 2048), ("vo  (half)", 29952, 512, 2048), ("ve  (C3 packed)", 7436, 384, 1536),
-          ("ve  (padded)", 9984, 384, 1536), ("te", 9000, 256, 1024)]
+          ("ve  (padded)", 9984, 384, 1536), ("ve  (2 batches)", 14872, 384, 1536)]
 for name, M, C, I in shapes:
     # interleave the two arms (rule: A/B in one process, alternating)
     f, u = [], []
