@@ -11,7 +11,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall 
 KERNELS := $(CSRC)/kernels_gemm.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_attn.hip $(CSRC)/kernels_xattn.hip $(CSRC)/kernels_ffn.hip
 HOSTSRC := $(CSRC)/engine.cpp $(CSRC)/api.cpp $(wildcard $(CSRC)/host/*.cpp)
 OBJS    := $(patsubst %.hip,build/%.o,$(KERNELS)) $(patsubst %.cpp,build/%.o,$(HOSTSRC))
-HDRS    := $(wildcard $(CSRC)/*.hpp $(CSRC)/host/*.hpp include/*.h)
+HDRS    := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.inc $(CSRC)/host/*.hpp include/*.h)
 
 all: supertonic_amd/libstn.so supertonic_amd/example_native oracle
 

@@ -458,7 +458,7 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     const auto fw = ffn_w_.find(p.pw1.w.as(dt_));
     if ((fused_ffn_ & stage_bit) && fw != ffn_w_.end() && ffn_fused_supported(dt_, C, hid) && M * C * 2 < 0x7FFFFFFFll) {
         FfnArgs fa;
-        fa.xn = xn; fa.ldx = C; fa.w1f = fw->second.w1f; fa.w2f = fw->second.w2f; fa.b1 = p.pw1.b; fa.b2 = p.pw2.b; fa.gamma = p.gamma;
+        fa.xn = xn; fa.ldx = C; fa.wseq = fw->second.wseq; fa.b1 = p.pw1.b; fa.b2 = p.pw2.b; fa.gamma = p.gamma;
         fa.x = x; fa.ldo = C; fa.M = (int)M; fa.I = hid; fa.rowvec = rowvec; fa.rv_ld = rv_ld;
         fa.row_b = (rg && rowvec) ? rg->row_b : nullptr;
         fa.len = rg ? nullptr : len; fa.L = L;
@@ -765,17 +765,22 @@ void Engine::prepare_xattn_weights() {
 void Engine::prepare_ffn_weights() {
     ffn_w_.clear();
     const stn_arch& a = a_;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
     auto add = [&](const std::string& p, int C, int hid) {
         if (!ffn_fused_supported(dt_, C, hid)) return;
         const ConvNeXt c = convnext_w(p);
-        void *w1f = nullptr, *w2f = nullptr;
-        STN_HIP(hipMalloc(&w1f, (size_t)hid * C * 2));
-        owned_.push_back(w1f);
-        STN_HIP(hipMalloc(&w2f, (size_t)hid * C * 2));
-        owned_.push_back(w2f);
-        launch_repack_frag(s_, c.pw1.w.as(dt_), hid, C, w1f);
-        launch_repack_frag_acc(s_, c.pw2.w.as(dt_), C, hid, w2f);
-        ffn_w_[c.pw1.w.as(dt_)] = FfnW{w1f, w2f};
+        void* wseq = nullptr;
+        STN_HIP(hipMalloc(&wseq, (size_t)2 * hid * C * 2));
+        owned_.push_back(wseq);
+        if ((size_t)2 * hid * C * 2 > tmp_bytes) {
+            if (tmp) (void)hipFree(tmp);
+            tmp_bytes = (size_t)2 * hid * C * 2;
+            STN_HIP(hipMalloc(&tmp, tmp_bytes));
+        }
+        launch_ffn_pack(s_, c.pw1.w.as(dt_), c.pw2.w.as(dt_), C, hid, tmp, wseq);
+        sync();  // tmp is reused by the next block
+        ffn_w_[c.pw1.w.as(dt_)] = FfnW{wseq};
     };
     auto S = [](const char* fmt, int i, int j = 0) { char b[64]; snprintf(b, sizeof b, fmt, i, j); return std::string(b); };
     for (int i = 0; i < a.dp_conv_blocks; ++i) add(S("dp.conv%d", i), a.dp_dim, a.dp_hidden);
@@ -788,6 +793,7 @@ void Engine::prepare_ffn_weights() {
     for (int j = 0; j < a.ve_tail_blocks; ++j) add(S("ve.tail%d", j), a.ve_dim, a.ve_hidden);
     for (int i = 0; i < a.vo_blocks; ++i) add(S("vo.blk%d", i), a.vo_dim, a.vo_hidden);
     sync();
+    if (tmp) (void)hipFree(tmp);
 }
 
 void Engine::prepare_vocoder_constants() {
@@ -1460,12 +1466,11 @@ void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const
     launch_cast(s_, dt_, d_w1, (int64_t)I * C, w1_16);
     launch_cast(s_, dt_, d_w2, (int64_t)I * C, w2_16);
     if (fused) {
-        void* w1f = act_alloc((int64_t)I * C);
-        void* w2f = act_alloc((int64_t)I * C);
-        launch_repack_frag(s_, w1_16, I, C, w1f);
-        launch_repack_frag_acc(s_, w2_16, C, I, w2f);
+        void* tmp = act_alloc((int64_t)2 * I * C);
+        void* wseq = act_alloc((int64_t)2 * I * C);
+        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq);
         FfnArgs fa;
-        fa.xn = xn16; fa.ldx = C; fa.w1f = w1f; fa.w2f = w2f; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
+        fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
         fa.M = M; fa.I = I; fa.rowvec = d_rv; fa.rv_ld = C; fa.row_b = d_rb; fa.L = M;
         launch_ffn_fused(s_, dt_, C, fa);
     } else {
@@ -1504,17 +1509,19 @@ void Engine::op_ffn_bench(int M, int C, int I, bool fused, int iters, double* ou
     launch_fill(s_, d_b1, I, 0.01f); launch_fill(s_, d_b2, C, 0.01f); launch_fill(s_, d_g, C, 0.1f);
     float* d_x = f32_alloc((int64_t)M * C);
     STN_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)M * C, s_));
-    void* w1f = act_alloc((int64_t)I * C);
-    void* w2f = act_alloc((int64_t)I * C);
-    launch_repack_frag(s_, w1_16, I, C, w1f);
-    launch_repack_frag_acc(s_, w2_16, C, I, w2f);
+    void* wseq = nullptr;
+    if (fused) {
+        void* tmp = act_alloc((int64_t)2 * I * C);
+        wseq = act_alloc((int64_t)2 * I * C);
+        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq);
+    }
     void* u = fused ? nullptr : act_alloc((int64_t)M * I);
     const int nwg = (M + 127) / 128;
     unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
     auto run = [&](unsigned long long* stamps) {
         if (fused) {
             FfnArgs fa;
-            fa.xn = xn16; fa.ldx = C; fa.w1f = w1f; fa.w2f = w2f; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
+            fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
             fa.M = M; fa.I = I; fa.L = M; fa.ts = stamps;
             launch_ffn_fused(s_, dt_, C, fa);
         } else {

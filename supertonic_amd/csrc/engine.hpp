@@ -112,7 +112,7 @@ class Engine {
     std::unordered_map<const void*, const void*> frag_w_;  // row-major 16-bit matrix -> its fragment-ordered copy
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
     void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
-    struct FfnW { const void* w1f = nullptr; const void* w2f = nullptr; };
+    struct FfnW { const void* wseq = nullptr; };
     std::unordered_map<const void*, FfnW> ffn_w_;  // key: the block's row-major 16-bit pw1 matrix
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------

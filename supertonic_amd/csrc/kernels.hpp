@@ -96,8 +96,8 @@ void launch_gemm_splitk(hipStream_t s, int dtype, const void* A, int lda, const 
 // 16-bit modes; W1 / W2 pre-packed once at model load (launch_repack_frag / launch_repack_frag_acc).
 struct FfnArgs {
     const void* xn = nullptr; int ldx = 0;        // LayerNorm output [M][ldx], 16-bit activation format
-    const void* w1f = nullptr;                    // W1 [I][C] in MFMA fragment order (launch_repack_frag)
-    const void* w2f = nullptr;                    // W2 [C][I] in accumulator-operand fragment order (launch_repack_frag_acc)
+    const void* wseq = nullptr;                   // both matrices in fragment order, interleaved in the order the kernel consumes
+                                                  // them (launch_ffn_pack): 2 * I * C 16-bit values
     const float* b1 = nullptr;                    // [I]
     const float* b2 = nullptr;                    // [C] or null
     const float* gamma = nullptr;                 // [C] layer scale or null
@@ -112,6 +112,11 @@ bool ffn_fused_supported(int dtype, int C, int I);
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a);
 // W [N][K] row-major 16-bit -> A fragments whose k order matches a GELU'd accumulator used as the B operand (N % 32, K % 32 == 0)
 void launch_repack_frag_acc(hipStream_t s, const void* W, int N, int K, void* Wf);
+// W1 [I][C], W2 [C][I] (row-major 16-bit) -> wseq: hidden tile t of W1 as C/16 KiB fragment pieces, hidden tile t of W2 as
+// C/16 KiB pieces in the accumulator-operand order, laid out as the stage sequence W1(0), W1(1), W2(0), W1(2), W2(1), ...,
+// W1(T-1), W2(T-2), W2(T-1) (T = I/32): the kernel's LDS-DMA stream is then one linear walk through memory.
+// tmp: 2 * I * C 16-bit values of scratch.
+void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq);
 
 // depthwise 'same' conv (taps k, dilation dil, weights TRANSPOSED [k][C]) fused with LayerNorm over C.
 // x fp32 [B*L][C] -> y act [B*L][C].  C % 4 == 0, C <= 1024.

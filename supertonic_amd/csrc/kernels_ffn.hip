@@ -99,19 +99,6 @@ namespace v_nord {
 #undef STN_V_NOGELU
 #undef STN_V_EARLYRD
 }
-namespace v_acca {
-#define STN_V_NODMA 0
-#define STN_V_NOGELU 0
-#define STN_V_EARLYRD 0
-#undef STN_V_ACCA
-#define STN_V_ACCA 1
-#include "kernels_ffn_body.inc"
-#undef STN_V_ACCA
-#define STN_V_ACCA 0
-#undef STN_V_NODMA
-#undef STN_V_NOGELU
-#undef STN_V_EARLYRD
-}
 namespace v_bare {
 #define STN_V_NODMA 1
 #define STN_V_NOGELU 1
@@ -148,6 +135,23 @@ void launch_repack_frag_acc(hipStream_t s, const void* W, int N, int K, void* Wf
                 static_cast<uint16_t*>(Wf));
 }
 
+void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf);  // kernels_xattn.hip
+
+void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq) {
+    if (C % 64 || I % 64) throw std::invalid_argument("launch_ffn_pack: C % 64 and I % 64 must be 0");
+    const size_t SB = (size_t)C * 64, T = (size_t)I / 32;
+    unsigned char* t1 = static_cast<unsigned char*>(tmp);
+    unsigned char* t2 = t1 + (size_t)I * C * 2;
+    launch_repack_frag(s, W1, I, C, t1);       // hidden tile t = bytes [t*SB, (t+1)*SB)
+    launch_repack_frag_acc(s, W2, C, I, t2);   // likewise
+    unsigned char* out = static_cast<unsigned char*>(wseq);
+    for (size_t v = 0; v < 2 * T; ++v) {
+        const bool w2 = v == 2 * T - 1 || (v >= 2 && (v & 1) == 0);
+        const size_t tile = v == 0 ? 0 : v == 2 * T - 1 ? T - 1 : w2 ? (v - 2) / 2 : (v + 1) / 2;
+        stn_check_hip(hipMemcpyAsync(out + v * SB, (w2 ? t2 : t1) + tile * SB, SB, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(ffn_pack)");
+    }
+}
+
 bool ffn_fused_supported(int dtype, int C, int I) {
     // bf16 only: the GELU inside the asm blocks is the bf16 form of the pw1 epilogue (half keeps the erf form and stays unfused)
     return dtype == BF16 && (C == 384 || C == 512) && I % 64 == 0 && I >= 128 && I <= 8192;
@@ -171,7 +175,6 @@ static void launch_ffn_t(hipStream_t s, const FfnArgs& a) {
     if (var == 3) { go(&v_earlyrd::ffn_fused_kernel<C>); return; }
     if (var == 4) { go(&v_bare::ffn_fused_kernel<C>); return; }
     if (var == 5) { go(&v_nord::ffn_fused_kernel<C>); return; }
-    if constexpr (C == 384) { if (var == 6) { go(&v_acca::ffn_fused_kernel<C>); return; } }
     STN_KLAUNCH((ffn_fused_kernel<C>), grid, dim3(256), lds, s, a);
 }
 
