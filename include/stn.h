@@ -97,8 +97,12 @@ int stn_batch_upload(stn_handle* h, int B, int Lt, const int64_t* text_ids, cons
 int stn_batch_set_noise(stn_handle* h, const float* noise /*[B,D,L]*/, int L);
 int stn_batch_run(stn_handle* h, int total_step, float speed, uint64_t noise_seed);
 /* hipGraph replay of the post-duration pipeline (default on): a shape is captured the second time it is run and replayed
- * afterwards; stn_graph_replays counts replays (tests / diagnostics) */
+ * afterwards.  Up to 8 captured shapes are kept (least recently used out first), so callers that alternate a few shapes — the
+ * reference's call() chunk loop and n_test loop, cpp/helper.cpp:697-719, cpp/example_onnx.cpp:88 — replay all of them; loading
+ * weights on the handle drops every captured graph.  stn_graph_replays counts replays, stn_graphs_cached the graphs held
+ * (tests / diagnostics). */
 int stn_set_graph_mode(stn_handle* h, int on);
+int64_t stn_graphs_cached(const stn_handle* h);
 /* Vocoder treatment of the padding in stn_batch_run.  0 (default) = the reference's batched Run (cpp/helper.cpp:668-679):
  * all L*ccf frames of every utterance are decoded, the padding being zero latent.  1 = length-aware: each utterance's frames
  * end at its own latent length, so wav[b, :len_b] is what a batch-of-one synthesis of utterance b gives — the mode in which

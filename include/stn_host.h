@@ -7,6 +7,7 @@
  *   stn_chunk_text         chunkText                                  cpp/helper.cpp:1117-1186
  *   stn_sanitize_filename  sanitizeFilename                           cpp/helper.cpp:1070-1111
  *   stn_wav_encode / stn_write_wav   writeWavFile                     cpp/helper.cpp:943-990
+ *   stn_load_voice_style   loadVoiceStyle                             cpp/helper.cpp:829-897 (schema go/helper.go:87-98)
  * Strings are UTF-8, NUL-terminated.  Functions that produce text return the number of bytes needed
  * (excluding the NUL) and write at most `cap` bytes; a negative return is an STN_ERR_* code and
  * stn_host_last_error() holds the message (thread-local).
@@ -43,6 +44,13 @@ int64_t stn_onnx_summary(const char* path, char* out, size_t cap);
 
 int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap);
 int stn_write_wav(const char* path, const float* audio, size_t n, int sample_rate);
+
+/* Voice-style JSON files {"style_ttl": {"data": [[[..]]], "dims": [1, d1, d2]}, "style_dp": {...}} stacked along dim 0 in the
+ * order given, row-major: ttl_out [n][d1][d2], dp_out [n][e1][e2].  dims6 = {n, d1, d2, n, e1, e2} (the first file's dims define
+ * the layout, as in the reference).  Call with null outputs (or capacities too small: nothing is written) to learn the dims.
+ * Errors ("Failed to open voice style file: <path>", data that does not match dims) come back as a negative code. */
+int stn_load_voice_style(const char* const* paths, int n, float* ttl_out, size_t ttl_cap_floats, float* dp_out, size_t dp_cap_floats,
+                         int64_t* dims6);
 
 #ifdef __cplusplus
 }

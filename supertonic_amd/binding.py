@@ -70,6 +70,8 @@ def load():
     L.stn_batch_vo_rows.restype = ctypes.c_int64
     L.stn_graph_replays.restype = ctypes.c_int64
     L.stn_graph_replays.argtypes = [vp]
+    L.stn_graphs_cached.restype = ctypes.c_int64
+    L.stn_graphs_cached.argtypes = [vp]
     L.stn_batch_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
     L.stn_batch_fetch.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
@@ -248,6 +250,10 @@ class Engine:
     @property
     def graph_replays(self):
         return self._lib.stn_graph_replays(self._h)
+
+    @property
+    def graphs_cached(self):
+        return self._lib.stn_graphs_cached(self._h)
 
     def batch_dims(self):
         B, L, W = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()

@@ -251,6 +251,7 @@ int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_
 int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 7, "stage mask must be in 0..7"); h->eng->set_fused_ffn(mask); }) }
 int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }
 int64_t stn_graph_replays(const stn_handle* h) { return h ? h->eng->graph_replays() : 0; }
+int64_t stn_graphs_cached(const stn_handle* h) { return h ? (int64_t)h->eng->graphs_cached() : 0; }
 int stn_batch_dims(const stn_handle* h, int* B, int* L, int64_t* wav_len) {
     if (!h) return STN_ERR_INVALID;
     const auto& b = h->eng->batch();

@@ -54,6 +54,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--device" && more) opts.device = std::atoi(argv[++i]);
         else if (a == "--dtype" && more) { const std::string d = argv[++i]; opts.dtype = d == "fp32" ? STN_DTYPE_F32 : d == "fp16" ? STN_DTYPE_F16 : STN_DTYPE_BF16; }
         else if (a == "--seed" && more) opts.noise_seed = std::strtoull(argv[++i], nullptr, 10);
+        else if (a == "--synthetic") opts.allow_synthetic = true;  // no model assets: run the default architecture on synthetic weights
     }
     if (voice_style.size() != text.size()) {
         std::cerr << "Error: Number of voice styles (" << voice_style.size() << ") must match number of texts (" << text.size() << ")\n";
@@ -69,10 +70,13 @@ int main(int argc, char* argv[]) {
         std::cout << std::endl;
         stn_arch arch;
         stn_get_arch(tts->engine(), &arch);
-        bool all_files = true;
-        for (auto& p : voice_style) all_files = all_files && exists(p);
-        const Style style = all_files ? loadVoiceStyle(voice_style, true) : syntheticVoiceStyle(voice_style, arch);
-        if (!all_files) std::cout << "Voice style files not found -> synthetic styles keyed by name" << std::endl;
+        // voice styles are files (loadVoiceStyle throws on a missing one, cpp/helper.cpp:835); only an engine on synthetic
+        // weights, given NO existing file at all, maps the names to deterministic synthetic styles
+        bool any_file = false;
+        for (auto& p : voice_style) any_file = any_file || exists(p);
+        const bool by_name = tts->synthetic() && !any_file;
+        const Style style = by_name ? syntheticVoiceStyle(voice_style, arch) : loadVoiceStyle(voice_style, true);
+        if (by_name) std::cout << "Voice style files not found -> synthetic styles keyed by name" << std::endl;
         make_dirs(save_dir);
         for (int n = 0; n < n_test; ++n) {
             std::cout << "\n[" << (n + 1) << "/" << n_test << "] Starting synthesis...\n";

@@ -115,7 +115,20 @@ void Engine::set_stream(hipStream_t s) {
     s_ = s ? s : own_s_;
 }
 
+void Engine::drop_graphs() {
+    for (auto& g : graphs_) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    graphs_.clear();
+    warm_keys_.clear();
+}
+
 void Engine::free_weights() {
+    // captured graphs point into the weights (and into the vocoder constants) that are about to be freed: none may survive
+    if (s_) (void)hipStreamSynchronize(s_);
+    drop_graphs();
+    ++wgen_;
     for (void* p : owned_) (void)hipFree(p);
     owned_.clear();
     w_.clear();
@@ -135,8 +148,7 @@ Engine::~Engine() {
     if (vo_edge_) (void)hipFree(vo_edge_);
     for (auto& sp : spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
-    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-    if (graph_) (void)hipGraphDestroy(graph_);
+    drop_graphs();
     if (pin_llen_) (void)hipHostFree(pin_llen_);
     if (pin_seed_) (void)hipHostFree(pin_seed_);
     if (seed_dev_) (void)hipFree(seed_dev_);
@@ -195,6 +207,43 @@ std::vector<std::string> Engine::tensor_names(const stn_arch& a) {
 }
 
 void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<std::string>* names_only) {
+    // the descriptor is caller data (tts.json, a manifest, a test): everything a kernel's contract depends on is checked here,
+    // with the field's name, so that a graph the engine cannot run is an error code at load time and never a failed launch
+    {
+        auto bad = [](const std::string& what) { throw std::invalid_argument("unsupported architecture descriptor: " + what); };
+        auto pos = [&](const char* n, int v) { if (v <= 0) bad(std::string(n) + " = " + std::to_string(v) + " (must be > 0)"); };
+        auto width = [&](const char* n, int v) {
+            pos(n, v);
+            if (v % 8) bad(std::string(n) + " = " + std::to_string(v) + " (widths must be multiples of 8: 16-byte rows)");
+            if (v > 1024) bad(std::string(n) + " = " + std::to_string(v) + " (LayerNorm / depthwise kernels hold a row of <= 1024 channels)");
+        };
+        auto hidden = [&](const char* n, int v) {  // widths that only feed GEMMs
+            pos(n, v);
+            if (v % 8 || v > 16384) bad(std::string(n) + " = " + std::to_string(v) + " (hidden widths: multiples of 8, <= 16384)");
+        };
+        auto heads = [&](const char* n, int c, int h) {
+            pos(n, h);
+            if (c % h || (c / h) % 8 || c / h < 8 || c / h > 96) bad(std::string(n) + " = " + std::to_string(h) + " (head dim " + std::to_string(c / std::max(h, 1)) + ": multiple of 8 in [8, 96])");
+        };
+        auto kern = [&](const char* n, int k) { if (k < 1 || k > 15 || !(k & 1)) bad(std::string(n) + " = " + std::to_string(k) + " (odd, <= 15)"); };
+        pos("sample_rate", a.sample_rate); pos("base_chunk_size", a.base_chunk_size); pos("chunk_compress_factor", a.chunk_compress_factor);
+        pos("latent_dim", a.latent_dim); pos("vocab_size", a.vocab_size);
+        pos("n_style_ttl", a.n_style_ttl); width("d_style_ttl", a.d_style_ttl); pos("n_style_dp", a.n_style_dp); width("d_style_dp", a.d_style_dp);
+        width("te_dim", a.te_dim); hidden("te_hidden", a.te_hidden); hidden("te_ffn", a.te_ffn); width("te_out_dim", a.te_out_dim);
+        width("dp_dim", a.dp_dim); hidden("dp_hidden", a.dp_hidden); width("ve_dim", a.ve_dim); hidden("ve_hidden", a.ve_hidden);
+        width("vo_dim", a.vo_dim); hidden("vo_hidden", a.vo_hidden); width("ve_time_dim", a.ve_time_dim);
+            heads("te_heads", a.te_dim, a.te_heads); heads("dp_heads", a.dp_dim, a.dp_heads); heads("ve_heads", a.ve_dim, a.ve_heads);
+        kern("te_kernel", a.te_kernel); kern("dp_kernel", a.dp_kernel); kern("ve_kernel", a.ve_kernel); kern("vo_kernel", a.vo_kernel); kern("vo_in_kernel", a.vo_in_kernel);
+        if (a.te_conv_blocks < 0 || a.te_attn_blocks < 0 || a.te_style_blocks < 0 || a.dp_conv_blocks < 0 || a.ve_main_blocks < 0 || a.ve_dilated < 0 ||
+            a.ve_tail_blocks < 0 || a.vo_blocks < 0) bad("a block count is negative");
+        if (a.ve_dilated > 8) bad("ve_dilated = " + std::to_string(a.ve_dilated) + " (dilations 2^j, j < 8)");
+        if (a.vo_blocks > STN_MAX_VO_BLOCKS) bad("vo_blocks = " + std::to_string(a.vo_blocks) + " exceeds STN_MAX_VO_BLOCKS");
+        for (int i = 0; i < a.vo_blocks; ++i)
+            if (a.vo_dilations[i] < 1 || a.vo_dilations[i] > 64) bad("vo_dilations[" + std::to_string(i) + "] = " + std::to_string(a.vo_dilations[i]));
+        if (a.base_chunk_size % 4) bad("base_chunk_size = " + std::to_string(a.base_chunk_size) + " (multiple of 4: 16-byte waveform rows)");
+        if (a.ve_time_dim % 2) bad("ve_time_dim must be even (sin/cos pairs)");
+        if (!(a.ln_eps > 0.f)) bad("ln_eps must be > 0");
+    }
     if (!names_only) {
         STN_HIP(hipSetDevice(device_));
         sync();
@@ -202,9 +251,6 @@ void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<s
         a_ = a;
     }
     const int D = a.latent_dim * a.chunk_compress_factor;
-    if (a.te_dim % a.te_heads || a.dp_dim % a.dp_heads || a.ve_dim % a.ve_heads)
-        throw std::runtime_error("model width must be divisible by the head count");
-    if (a.vo_blocks > STN_MAX_VO_BLOCKS) throw std::runtime_error("vo_blocks exceeds STN_MAX_VO_BLOCKS");
 
     std::unordered_map<std::string, std::vector<float>> host;  // canonical copies kept for derived tensors
     auto upload = [&](const std::string& name, const std::vector<float>& v, int rows, int cols, bool want_bf16) {
@@ -390,9 +436,7 @@ void Engine::prof_end() {
 }
 void Engine::profile_reset() {
     sync();
-    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }  // its event-record nodes reference pooled events
-    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
-    graph_key_ = GraphKey();
+    // (cached graphs stay: a shape is only ever captured with profiling off, so no graph holds a pooled event)
     for (auto& sp : spans_) { ev_pool_.push_back(sp.a); ev_pool_.push_back(sp.b); }
     spans_.clear();
 }
@@ -529,6 +573,10 @@ void Engine::attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, co
 // =================================================================================================
 void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_dp, const int* tlen, float* dur, const Ragged* trg) {
     stage_ = "dp";
+    // The predicted durations define L, every latent length, the returned durations and the audio trim point: the predictor
+    // always runs in exact fp32 (fp32 masters of its weights, exact-fp32 MFMA), whatever the engine's 16-bit mode, so that a
+    // bf16 / f16 engine returns the utterance lengths of the fp32 reference.  It is ~1 % of a batch.
+    struct DtGuard { int& r; int saved; DtGuard(int& x) : r(x), saved(x) { r = F32; } ~DtGuard() { r = saved; } } dt_guard(dt_);
     const stn_arch& a = a_;
     const int C = a.dp_dim;
     const int64_t M = trg ? (int64_t)trg->rows : (int64_t)B * Lt;
@@ -1101,11 +1149,14 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     ensure(b.xt[0], b.xt_cap[0], nx);
     ensure(b.xt[1], b.xt_cap[1], nx);
     ensure(b.wav, b.wav_cap, nw);
-    // per-call data of the captured region lives in pinned host memory (the graph's memcpy nodes re-read it at replay)
+    // per-call data of the captured region lives in pinned host memory (the graph's memcpy nodes re-read it at replay).
+    // Sized for 1024 utterances up front so that it is not reallocated under cached graphs; should it ever have to grow, its
+    // address is part of the graph key and the graphs that point at the old block are dropped before it is freed.
     if ((size_t)B > pin_llen_cap_) {
-        if (pin_llen_) { sync(); (void)hipHostFree(pin_llen_); }
-        STN_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin_llen_), sizeof(int) * (size_t)B, hipHostMallocDefault));
-        pin_llen_cap_ = (size_t)B;
+        if (pin_llen_) { sync(); drop_graphs(); (void)hipHostFree(pin_llen_); pin_llen_ = nullptr; }
+        const size_t cap = std::max<size_t>((size_t)B, 1024);
+        STN_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin_llen_), sizeof(int) * cap, hipHostMallocDefault));
+        pin_llen_cap_ = cap;
         pin_valid_ = false;
     }
     if (!pin_seed_) {
@@ -1115,7 +1166,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     }
     // a previous run's copy nodes may still be reading the staging: rewrite it only when the content changes, and then
     // only after the stream has drained (steady-state replays of an unchanged batch never wait here)
-    if (!std::equal(b.h_llen.begin(), b.h_llen.end(), pin_llen_) || *pin_seed_ != (unsigned long long)noise_seed || !pin_valid_) {
+    if (!pin_valid_ || !std::equal(b.h_llen.begin(), b.h_llen.end(), pin_llen_) || *pin_seed_ != (unsigned long long)noise_seed) {
         sync();
         std::copy(b.h_llen.begin(), b.h_llen.end(), pin_llen_);
         *pin_seed_ = (unsigned long long)noise_seed;
@@ -1123,7 +1174,8 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     }
 
     GraphKey key;
-    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.xattn = fused_xattn_; key.gen = b.gen;
+    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.xattn = fused_xattn_;
+    key.ffn = fused_ffn_; key.gen = b.gen; key.wgen = wgen_; key.pin = pin_llen_;
     key.rows = 0;
     if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;
     last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L;
@@ -1131,17 +1183,21 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     key.trows = tpk ? b.trows : 0;
     last_vo_rows_ = (int64_t)B * L * a.chunk_compress_factor;
     if (vo_ragged_ && packed_ve_ && is_half(dt_)) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
-    else if (key.vrows) last_vo_rows_ = key.vrows; key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
+    else if (key.vrows) last_vo_rows_ = key.vrows;
+    key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
     const bool graphable = graph_on_ && !prof_on_;
-    if (graphable && graph_exec_ && key == graph_key_) {
-        STN_HIP(hipGraphLaunch(graph_exec_, s_));
-        ++graph_replays_;
-        return;
+    if (graphable) {
+        for (auto& g : graphs_)
+            if (g.key == key) {
+                g.last_use = ++graph_clock_;
+                STN_HIP(hipGraphLaunch(g.exec, s_));
+                ++graph_replays_;
+                return;
+            }
     }
-    if (graphable && key == warm_key_) {  // second sighting of this shape: the arena is warm, allocation order is fixed
-        if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
-        if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    const auto warm = std::find(warm_keys_.begin(), warm_keys_.end(), key);
+    if (graphable && warm != warm_keys_.end()) {  // second sighting of this shape: the arena is warm, allocation order is fixed
         const Arena::Mark cap0 = ar_.mark();
         const size_t cap_before = ar_.capacity();
         STN_HIP(hipStreamBeginCapture(s_, hipStreamCaptureModeThreadLocal));
@@ -1151,20 +1207,32 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
         hipGraph_t g = nullptr;
         const hipError_t ec = hipStreamEndCapture(s_, &g);
         ar_.release(cap0);
-        if (ok && ec == hipSuccess && g && ar_.capacity() == cap_before && hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0) == hipSuccess) {
-            graph_ = g;
-            graph_key_ = key;
-            STN_HIP(hipGraphLaunch(graph_exec_, s_));
+        hipGraphExec_t ex = nullptr;
+        if (ok && ec == hipSuccess && g && ar_.capacity() == cap_before && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+            if (graphs_.size() >= kGraphCache) {  // evict the least recently used entry
+                auto lru = std::min_element(graphs_.begin(), graphs_.end(), [](const GraphEntry& x, const GraphEntry& y) { return x.last_use < y.last_use; });
+                sync();  // its last replay may still be running
+                (void)hipGraphExecDestroy(lru->exec);
+                (void)hipGraphDestroy(lru->graph);
+                graphs_.erase(lru);
+            }
+            GraphEntry e;
+            e.key = key; e.graph = g; e.exec = ex; e.last_use = ++graph_clock_;
+            graphs_.push_back(e);
+            warm_keys_.erase(warm);
+            STN_HIP(hipGraphLaunch(ex, s_));
             ++graph_replays_;
             return;
         }
         if (g) (void)hipGraphDestroy(g);
-        graph_exec_ = nullptr;
         (void)hipGetLastError();
         if (!ok) throw std::runtime_error("graph capture failed: " + why);
         // fall through to an eager run
     }
-    warm_key_ = key;
+    if (warm == warm_keys_.end()) {
+        if (warm_keys_.size() >= kWarmKeys) warm_keys_.erase(warm_keys_.begin());
+        warm_keys_.push_back(key);
+    }
     enqueue_after_duration(total_step);
 }
 

@@ -170,6 +170,7 @@ class Engine {
     }
     bool packed_rows_ok(int B) const { return packed_ve_ && B <= 1024 && a_.ve_dilated > 0 && dwconv_ln_supports_packed(a_.ve_dim, a_.ve_kernel); }
     long graph_replays() const { return graph_replays_; }
+    size_t graphs_cached() const { return graphs_.size(); }
     const Batch& batch() const { return bt_; }
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
     // waveform as 16-bit PCM (clamp, *32767, truncate: cpp/helper.cpp:986-987) converted on the GPU: half the D2H bytes
@@ -254,10 +255,25 @@ class Engine {
     template <typename T> void ensure(T*& p, size_t& cap, size_t need);
     std::vector<float> reported_dur_;
     void enqueue_after_duration(int total_step);
+    // A captured graph holds raw pointers: everything it can have baked in is part of its key — the batch buffers (`gen`, bumped
+    // by every reallocation), the weights (`wgen`, bumped by every load), the pinned staging the copy nodes read, the stream.
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false, xattn = false; int rows = 0, vrows = 0, trows = 0; uint64_t gen = 0; const void* p0 = nullptr; const void* p1 = nullptr; hipStream_t s = nullptr;
-        bool operator==(const GraphKey& o) const { return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && xattn == o.xattn && rows == o.rows && vrows == o.vrows && trows == o.trows && gen == o.gen && p0 == o.p0 && p1 == o.p1 && s == o.s; }
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false, xattn = false; int ffn = 0; int rows = 0, vrows = 0, trows = 0;
+        uint64_t gen = 0, wgen = 0; const void* p0 = nullptr; const void* p1 = nullptr; const void* pin = nullptr; hipStream_t s = nullptr;
+        bool operator==(const GraphKey& o) const {
+            return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && xattn == o.xattn && ffn == o.ffn &&
+                   rows == o.rows && vrows == o.vrows && trows == o.trows && gen == o.gen && wgen == o.wgen && p0 == o.p0 && p1 == o.p1 && pin == o.pin && s == o.s;
+        }
     };
+    // LRU cache of captured graphs (the reference's call() loop and the n_test loop alternate a few shapes,
+    // /root/reference/cpp/helper.cpp:697-719, cpp/example_onnx.cpp:88): a shape is captured the second time it is seen
+    // (`warm_keys_`: the arena must have seen its allocation sequence once) and replayed from then on.
+    struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
+    static constexpr size_t kGraphCache = 8, kWarmKeys = 16;
+    std::vector<GraphEntry> graphs_;
+    std::vector<GraphKey> warm_keys_;
+    uint64_t graph_clock_ = 0, wgen_ = 0;
+    void drop_graphs();  // destroy every cached graph (weights or staging they point at are going away)
     bool graph_on_ = true;
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
@@ -270,9 +286,6 @@ class Engine {
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }
     int vo_rf_ = 0;
     int trimmed_rows(int B, int L, std::vector<int>* n_host) const;  // sum of the trimmed extents (0: trimming not applicable)
-    GraphKey graph_key_, warm_key_;
-    hipGraphExec_t graph_exec_ = nullptr;
-    hipGraph_t graph_ = nullptr;
     long graph_replays_ = 0;
     int* pin_llen_ = nullptr; size_t pin_llen_cap_ = 0;   // pinned host staging read by the graph's memcpy node
     unsigned long long* pin_seed_ = nullptr;

@@ -8,6 +8,7 @@
 #include "../../../include/stn.h"
 #include "onnx_reader.hpp"
 #include "text_frontend.hpp"
+#include "tts_host.hpp"
 
 static thread_local std::string g_err;
 
@@ -114,6 +115,18 @@ int stn_write_wav(const char* path, const float* audio, size_t n, int sample_rat
         return STN_OK;
     });
     return rc == STN_OK ? STN_OK : STN_ERR_IO;
+}
+
+int stn_load_voice_style(const char* const* paths, int n, float* ttl_out, size_t ttl_cap, float* dp_out, size_t dp_cap, int64_t* dims6) {
+    return (int)guarded([&]() -> int64_t {
+        if (!paths || n <= 0 || !dims6) throw std::runtime_error("bad argument");
+        std::vector<std::string> p(paths, paths + n);
+        const stn::host::Style st = stn::host::loadVoiceStyle(p, false);
+        for (int i = 0; i < 3; ++i) { dims6[i] = st.getTtlShape()[i]; dims6[3 + i] = st.getDpShape()[i]; }
+        if (ttl_out && ttl_cap >= st.getTtlData().size()) std::memcpy(ttl_out, st.getTtlData().data(), sizeof(float) * st.getTtlData().size());
+        if (dp_out && dp_cap >= st.getDpData().size()) std::memcpy(dp_out, st.getDpData().data(), sizeof(float) * st.getDpData().size());
+        return STN_OK;
+    });
 }
 
 }  // extern "C"

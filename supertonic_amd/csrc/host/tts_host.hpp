@@ -47,7 +47,8 @@ Style syntheticVoiceStyle(const std::vector<std::string>& voice_names, const stn
 struct EngineOptions {
     int device = 0;
     int dtype = STN_DTYPE_BF16;
-    bool allow_synthetic = true;   // no assets -> descriptor weights instead of failing (bench / tests)
+    bool allow_synthetic = false;  // opt-in (CLI --synthetic, tests): no assets -> descriptor weights instead of the reference's
+                                   // error on unreadable assets (cpp/helper.cpp:805)
     uint64_t weight_seed = 7;
     uint64_t noise_seed = 0;       // 0 -> from std::random_device per call, like the unseeded reference
 };

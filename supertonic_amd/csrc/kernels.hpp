@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <stdexcept>
+#include <string>
 
 namespace stn {
 
@@ -37,9 +38,11 @@ struct PerDeviceOnce {
 };
 
 // launch-side HIP calls that must not fail silently (a failed attribute call leaves a sticky error that surfaces in
-// whatever library checks hipGetLastError next)
+// whatever library checks hipGetLastError next).  Nothing in this library calls abort(): contract violations and HIP failures
+// are exceptions, which the C ABI (api.cpp) turns into STN_ERR_INVALID / STN_ERR_DEVICE + stn_last_error — the reference's
+// hosts get std::runtime_error from the same situations (/root/reference/cpp/helper.cpp:479-481, 193).
 inline void stn_check_hip(hipError_t e, const char* what) {
-    if (e != hipSuccess) { fprintf(stderr, "stn: %s failed: %s\n", what, hipGetErrorString(e)); abort(); }
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + what + " failed: " + hipGetErrorString(e));
 }
 
 

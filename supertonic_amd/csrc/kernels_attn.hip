@@ -435,8 +435,8 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
                       int ldo, int B, int Lq, int Lk, int H, int dh, const int* qlen, const int* klen, int rope_mode,
                       float rope_base, float rope_gamma, bool k_rotated, const int* q_off, const int* k_off) {
     if (B == 0 || Lq == 0) return;
-    if ((q_off && !qlen) || (k_off && !klen)) { fprintf(stderr, "stn: packed attention needs the lengths of the packed side\n"); abort(); }
-    if (dh > ADH_MAX || dh % 8 || dh < 8) { fprintf(stderr, "stn: attention head dim %d unsupported (multiple of 8, <= %d)\n", dh, ADH_MAX); abort(); }
+    if ((q_off && !qlen) || (k_off && !klen)) { throw std::invalid_argument("packed attention needs the lengths of the packed side"); }
+    if (dh > ADH_MAX || dh % 8 || dh < 8) { char m_[256]; snprintf(m_, sizeof m_, "attention head dim %d unsupported (multiple of 8, <= %d)", dh, ADH_MAX); throw std::invalid_argument(m_); }
     if (is_half(dtype) && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
         !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
         // keys go through LDS in chunks of at most 128 (one chunk covers the 50 style tokens and ~100-token texts; longer texts

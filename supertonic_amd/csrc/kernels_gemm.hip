@@ -816,7 +816,7 @@ static void launch_tiled(hipStream_t s, const void* A, int lda, const void* W, i
     }
     const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_, ntiles = tiles_m * tiles_n;
     const int ksp = e.ksplit > 1 ? e.ksplit : 1;
-    if (ksp > 1 && (MODE != EPI_STORE || (K / KS) % ksp != 0)) { fprintf(stderr, "stn: split-K needs a plain store epilogue and K/KS divisible by the split\n"); abort(); }
+    if (ksp > 1 && (MODE != EPI_STORE || (K / KS) % ksp != 0)) { throw std::invalid_argument("split-K needs a plain store epilogue and K/KS divisible by the split"); }
     STN_KLAUNCH((gemm_tiled_kernel<MODE, BM_, BN_, WM, WN, NSTAGE, KS, ESZ, F16>), dim3(ntiles * ksp), dim3(WM * WN * 64), lds, s, A, lda,
                        W, ldw, M, N, K, tiles_n, ntiles, e);
 }
@@ -896,11 +896,8 @@ void launch_gemm(hipStream_t s, int dtype, const void* A, int lda, const void* W
     if (M <= 0 || N <= 0) return;
     const int kq = is_half(dtype) ? 8 : 4;
     if (K <= 0 || K % kq || lda % kq || ldw % kq || (reinterpret_cast<uintptr_t>(A) & 15) ||
-        (reinterpret_cast<uintptr_t>(W) & 15)) {
-        fprintf(stderr, "stn: launch_gemm: operand shape/alignment violates the kernel contract (K=%d lda=%d ldw=%d)\n", K,
-                lda, ldw);
-        abort();
-    }
+        (reinterpret_cast<uintptr_t>(W) & 15)) { char m_[256]; snprintf(m_, sizeof m_, "launch_gemm: operand shape/alignment violates the kernel contract (K=%d lda=%d ldw=%d)", K,
+                lda, ldw); throw std::invalid_argument(m_); }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
     // v2 ring kernel: bf16, K % 32 == 0.  Vectorised epilogue needs 16-B aligned 8-column groups.
     const bool ring = is_half(dtype) && K % RK == 0;

@@ -373,7 +373,7 @@ static bool launch_dwconv_ln_v2(hipStream_t s, const float* x, int64_t M, int L,
 }
 
 static void check_ln_shape(int C) {
-    if (C % 4 || C > 4 * 64 * LN_NI) { fprintf(stderr, "stn: LayerNorm width %d unsupported (C %% 4 == 0, C <= 1024)\n", C); abort(); }
+    if (C % 4 || C > 4 * 64 * LN_NI) { char m_[256]; snprintf(m_, sizeof m_, "LayerNorm width %d unsupported (C %% 4 == 0, C <= 1024)", C); throw std::invalid_argument(m_); }
 }
 
 bool dwconv_ln_supports_packed(int C, int k) { return C <= 512 && C % 4 == 0 && (k == 5 || k == 7); }
@@ -384,7 +384,7 @@ void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L
     check_ln_shape(C);
     const int64_t M = (int64_t)B * L;
     if (M == 0) return;
-    if (row_off && (!seqlen || !dwconv_ln_supports_packed(C, k))) { fprintf(stderr, "stn: packed dwconv_ln needs lengths, C <= 512, k in {5,7}\n"); abort(); }
+    if (row_off && (!seqlen || !dwconv_ln_supports_packed(C, k))) { throw std::invalid_argument("packed dwconv_ln needs lengths, C <= 512, k in {5,7}"); }
     if (out_dtype == BF16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<uint16_t*>(y), seqlen, row_off)
         : out_dtype == F16 ? launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<f16_t*>(y), seqlen, row_off)
                           : launch_dwconv_ln_v3(s, x, B, L, C, w_t, bias, k, dil, ln_g, ln_b, eps, static_cast<float*>(y), seqlen, row_off))
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict_
 void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out,
                       const int* row_off) {
     if (B * D * L == 0) return;
-    if (row_off && !len) { fprintf(stderr, "stn: packed euler_ncl needs lengths\n"); abort(); }
+    if (row_off && !len) { throw std::invalid_argument("packed euler_ncl needs lengths"); }
     STN_KLAUNCH(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off);
 }
 
@@ -550,12 +550,12 @@ __global__ void unpack_rows_kernel(const float* __restrict__ src, const int* __r
 void launch_unpack_rows(hipStream_t s, const float* src, const int* len, const int* row_off, int B, int T, int W, float* dst) {
     const int64_t n4 = (int64_t)B * T * (W / 4);
     if (n4 == 0) return;
-    if (W % 4) { fprintf(stderr, "stn: unpack_rows needs W %% 4 == 0\n"); abort(); }
+    if (W % 4) { throw std::invalid_argument("unpack_rows needs W % 4 == 0"); }
     STN_KLAUNCH(unpack_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, len, row_off, T, W / 4, n4, dst);
 }
 void launch_row_map(hipStream_t s, const int* len, int B, int* row_off, int* row_b) {
     if (B <= 0) return;
-    if (B > 1024) { fprintf(stderr, "stn: packed layout supports at most 1024 sequences per batch\n"); abort(); }
+    if (B > 1024) { throw std::invalid_argument("packed layout supports at most 1024 sequences per batch"); }
     STN_KLAUNCH(row_map_kernel, dim3(1), dim3(1024), 0, s, len, B, row_off, row_b);
 }
 
@@ -588,7 +588,7 @@ __global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict
 void launch_add_rowvec(hipStream_t s, float* x, const float* v, int ldv, int B, int L, int C, const int* len) {
     const int64_t n4 = (int64_t)B * L * (C / 4);
     if (n4 == 0) return;
-    if (C % 4 || ldv % 4) { fprintf(stderr, "stn: add_rowvec needs C %% 4 == 0\n"); abort(); }
+    if (C % 4 || ldv % 4) { throw std::invalid_argument("add_rowvec needs C % 4 == 0"); }
     STN_KLAUNCH(add_rowvec_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, v, ldv, L, C / 4, n4, len);
 }
 
@@ -856,7 +856,7 @@ void launch_unpack_rows_quiet(hipStream_t s, const float* src, const int* valid,
                               const float* quiet, const float* edge, float* dst) {
     const int64_t n4 = (int64_t)B * T * (W / 4);
     if (n4 == 0) return;
-    if (W % 4) { fprintf(stderr, "stn: unpack_rows needs W %% 4 == 0\n"); abort(); }
+    if (W % 4) { throw std::invalid_argument("unpack_rows needs W % 4 == 0"); }
     STN_KLAUNCH(unpack_rows_quiet_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, valid, row_off, T, W / 4, rf, quiet, edge,
                 n4, dst);
 }

@@ -489,7 +489,7 @@ void launch_one(hipStream_t s, float* x, const float* ln_g, const float* ln_b, f
 }  // namespace
 
 void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf) {
-    if (N % 32 || K % 16) { fprintf(stderr, "stn: launch_repack_frag: N %% 32 and K %% 16 must be 0\n"); abort(); }
+    if (N % 32 || K % 16) { throw std::invalid_argument("launch_repack_frag: N % 32 and K % 16 must be 0"); }
     const int64_t n = (int64_t)(N / 32) * (K / 16) * 64;
     STN_KLAUNCH(repack_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const uint16_t*>(W), N, K, static_cast<uint16_t*>(Wf));
 }
@@ -503,10 +503,7 @@ void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, c
                         const int* qlen, const int* klen, const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma) {
     if (B == 0 || L == 0) return;
     if (!xattn_fused_supported(dtype, C, H, Lk, ldk) || (q_off && !qlen) || (k_off && !klen) || (reinterpret_cast<uintptr_t>(kp) & 15) ||
-        (reinterpret_cast<uintptr_t>(vp) & 15) || (reinterpret_cast<uintptr_t>(Wq) & 15) || (reinterpret_cast<uintptr_t>(Wo) & 15)) {
-        fprintf(stderr, "stn: launch_xattn_fused: unsupported shape or alignment (callers check xattn_fused_supported)\n");
-        abort();
-    }
+        (reinterpret_cast<uintptr_t>(vp) & 15) || (reinterpret_cast<uintptr_t>(Wq) & 15) || (reinterpret_cast<uintptr_t>(Wo) & 15)) { throw std::invalid_argument("launch_xattn_fused: unsupported shape or alignment (callers check xattn_fused_supported)"); }
     const int kc = (Lk + 31) & ~31;
     const float lb = logf(rope_base);
     // rows per workgroup: the smallest tile that still leaves about two workgroups per CU, so short utterances spread over the chip

@@ -30,6 +30,8 @@ def _lib():
         L.stn_wav_encode.restype = i64
         L.stn_wav_encode.argtypes = [ctypes.c_void_p, sz, ctypes.c_int, ctypes.c_void_p, sz]
         L.stn_write_wav.argtypes = [c, ctypes.c_void_p, sz, ctypes.c_int]
+        L.stn_load_voice_style.argtypes = [ctypes.POINTER(c), ctypes.c_int, ctypes.c_void_p, sz, ctypes.c_void_p, sz,
+                                           ctypes.POINTER(ctypes.c_int64)]
         _READY = True
     return L
 
@@ -146,3 +148,17 @@ def write_wav_file(path: str, audio, sample_rate: int):
     a = np.ascontiguousarray(audio, np.float32)
     if L.stn_write_wav(path.encode(), a.ctypes.data, a.size, sample_rate) != 0:
         raise OSError(L.stn_host_last_error().decode())
+
+
+def load_voice_style_native(paths):
+    """loadVoiceStyle of the C++ host (cpp/helper.cpp:829-897) through the C ABI -> (ttl [n, d1, d2], dp [n, e1, e2])."""
+    L = _lib()
+    arr = (ctypes.c_char_p * len(paths))(*[_enc(p) for p in paths])
+    dims = (ctypes.c_int64 * 6)()
+    if L.stn_load_voice_style(arr, len(paths), None, 0, None, 0, dims) != 0:
+        raise OSError(L.stn_host_last_error().decode())
+    ttl = np.empty((dims[0], dims[1], dims[2]), np.float32)
+    dp = np.empty((dims[3], dims[4], dims[5]), np.float32)
+    if L.stn_load_voice_style(arr, len(paths), ttl.ctypes.data, ttl.size, dp.ctypes.data, dp.size, dims) != 0:
+        raise OSError(L.stn_host_last_error().decode())
+    return ttl, dp

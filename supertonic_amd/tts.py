@@ -126,9 +126,13 @@ def load_cfgs(onnx_dir):
         return json.load(f)
 
 
-def load_text_to_speech(onnx_dir, use_gpu=True, device=0, dtype="bf16", allow_synthetic=True, weight_seed=7, noise_seed=None):
-    """py/helper.py:316-337.  use_gpu=True is the only mode (the reference only had the CPU one).  When the asset directory is
-    unusable and `allow_synthetic` is set, the engine runs the default architecture on synthetic weights and says so."""
+def load_text_to_speech(onnx_dir, use_gpu=True, device=0, dtype="bf16", allow_synthetic=None, weight_seed=7, noise_seed=None):
+    """py/helper.py:316-337.  use_gpu=True is the only mode (the reference only had the CPU one).  An unusable asset directory is an
+    error, as in the reference (cpp/helper.cpp:805); only when the caller opts in — `allow_synthetic=True`, or TTS_ALLOW_SYNTHETIC=1
+    in the environment when the argument is left at None — does the engine fall back to the default architecture on synthetic
+    weights (benchmarks and tests on machines without the Hugging Face assets), and it says so."""
+    if allow_synthetic is None:
+        allow_synthetic = os.getenv("TTS_ALLOW_SYNTHETIC", "0").strip().lower() in {"1", "true", "yes", "y", "on"}
     if not use_gpu:
         raise NotImplementedError("CPU mode is not supported: this engine runs on MI355X only")
     eng = binding.Engine(device, dtype)

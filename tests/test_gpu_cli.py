@@ -27,7 +27,7 @@ def _wav(path):
 
 
 def _run(args, cwd):
-    p = subprocess.run([CLI] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    p = subprocess.run([CLI, "--synthetic"] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     return p.stdout
 
@@ -67,5 +67,32 @@ def test_long_form_chunks_and_silence(tmp_path):
 def test_mismatched_counts_exit_code(tmp_path):
     p = subprocess.run([CLI, "--batch", "--voice-style", "M1", "--text", "a|b", "--lang", "en,en"], cwd=tmp_path, capture_output=True, text=True)
     assert p.returncode == 1 and "must match number of texts" in p.stderr  # cpp/example_onnx.cpp:66-70
-    p = subprocess.run([CLI, "--text", "x", "--lang", "de", "--n-test", "1"], cwd=tmp_path, capture_output=True, text=True)
+    p = subprocess.run([CLI, "--synthetic", "--text", "x", "--lang", "de", "--n-test", "1"], cwd=tmp_path, capture_output=True, text=True)
     assert p.returncode == 2 and "Invalid language: de" in p.stderr  # cpp/helper.cpp:193
+
+
+def test_missing_assets_are_an_error_without_the_opt_in(tmp_path):
+    """cpp/helper.cpp:805: unreadable assets throw; synthetic weights are an explicit opt-in (--synthetic)."""
+    p = subprocess.run([CLI, "--onnx-dir", "no_assets_here", "--n-test", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "Saved: " not in p.stdout
+    assert "Failed to open" in (p.stdout + p.stderr)
+
+
+def test_voice_style_files_are_loaded(tmp_path):
+    """--voice-style with real paths goes through loadVoiceStyle (cpp/helper.cpp:829-897), not the synthetic-by-name styles."""
+    import json
+    rng = np.random.default_rng(3)
+    paths = []
+    for name in ("M1", "F1"):
+        p = tmp_path / f"{name}.json"
+        d = {"style_ttl": {"data": (rng.standard_normal((1, 50, 256)) * 0.1).astype(np.float32).tolist(), "dims": [1, 50, 256], "type": "float32"},
+             "style_dp": {"data": (rng.standard_normal((1, 8, 16)) * 0.1).astype(np.float32).tolist(), "dims": [1, 8, 16], "type": "float32"}}
+        p.write_text(json.dumps(d))
+        paths.append(str(p))
+    out = _run(["--batch", "--voice-style", ",".join(paths), "--text", "Hello there.|Good morning to you.", "--lang", "en,en",
+                "--n-test", "1", "--save-dir", "res", "--total-step", "2", "--seed", "5"], tmp_path)
+    assert "Loaded 2 voice styles" in out and "synthetic styles keyed by name" not in out and out.count("Saved: ") == 2
+    # a path that does not exist beside one that does is an error (the reference throws), not a silent synthetic style
+    p = subprocess.run([CLI, "--synthetic", "--batch", "--voice-style", paths[0] + "," + str(tmp_path / "missing.json"), "--text", "a|b", "--lang", "en,en",
+                        "--n-test", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0

@@ -134,3 +134,33 @@ def test_graph_replay_equals_eager(eng):
         eng.batch_run(2, 1.0, 12)
     g2, _ = eng.batch_fetch()
     assert np.array_equal(g2, wb)
+
+
+def test_contract_violations_are_error_codes_not_aborts():
+    """include/stn.h: every function returns STN_OK or a negative code.  A head dim the attention kernels do not support and a
+    descriptor wider than the LayerNorm kernels handle come back as STN_ERR_INVALID with a message — the process stays alive
+    (the reference throws std::runtime_error in the same situations, /root/reference/cpp/helper.cpp:479-481, 193)."""
+    from supertonic_amd.arch import default_arch
+    e = binding.Engine(0, "bf16")
+    q = np.zeros((1 * 4, 2 * 12), np.float32)
+    with pytest.raises(binding.StnError) as ei:
+        e.op_attention(q.reshape(1, 4, 24), q.reshape(1, 4, 24), q.reshape(1, 4, 24), H=2)
+    assert ei.value.code == -1 and "stn_op_attention" in str(ei.value)
+    a = default_arch()
+    a.vo_dim = 2048
+    with pytest.raises(binding.StnError) as ei:
+        e.load_synthetic(a, 7)
+    assert ei.value.code == -1 and "vo_dim = 2048" in str(ei.value)
+    a = default_arch()
+    a.ve_heads = 5  # 384 / 5 is not an integer head dim
+    with pytest.raises(binding.StnError) as ei:
+        e.load_synthetic(a, 7)
+    assert ei.value.code == -1 and "ve_heads" in str(ei.value)
+    # a GEMM whose K breaks the 16-byte row contract: the launcher throws, the ABI returns the code
+    with pytest.raises(binding.StnError):
+        e.op_gemm(np.zeros((8, 12), np.float32), np.zeros((8, 12), np.float32), dtype="bf16")
+    # the handle is still usable
+    e.load_synthetic(tiny_arch(), 7)
+    ids, mask, sttl, sdp = make_inputs(tiny_arch(), 1, 6, [6], seed=1)
+    w, _ = e.synthesize(ids, mask, sttl, sdp, 2, 1.0, duration_override=np.array([0.3], np.float32))
+    assert np.all(np.isfinite(w))

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def tts():
-    t = tts_mod.load_text_to_speech("no_assets_here", use_gpu=True, dtype="bf16", noise_seed=11)
+    t = tts_mod.load_text_to_speech("no_assets_here", use_gpu=True, dtype="bf16", noise_seed=11, allow_synthetic=True)
     assert t.synthetic and t.sample_rate == 44100
     return t
 
@@ -96,3 +96,11 @@ def test_service_end_to_end_and_dynamic_batching(tts):
         r = c.post("/tts", json={"text": texts[:2], "lang": langs[:2], "voice_style": ["a.json", "b.json"], "batch": True})
         assert r.status_code == 200 and r.headers["content-type"] == "application/zip"
         assert c.post("/tts", json={"text": "x", "lang": "de"}).json()["detail"] == "Invalid language(s): de"
+
+
+def test_missing_assets_fail_at_startup_by_default(monkeypatch):
+    """The service must not serve audio from random weights when the asset directory does not load (py/helper.py raises too)."""
+    from supertonic_amd import binding
+    monkeypatch.delenv("TTS_ALLOW_SYNTHETIC", raising=False)
+    with pytest.raises(binding.StnError):
+        tts_mod.load_text_to_speech("no_assets_here", use_gpu=True, dtype="bf16")
