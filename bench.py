@@ -8,8 +8,11 @@
 A "step" = one full synthesis of this rank's resident batch (DP -> text encoder -> noise -> 5x vector estimator ->
 vocoder) with every input already in HBM; for N > 1 the step also converts the waveforms to 16-bit PCM (what the
 reference writes to disk) and gathers them to rank 0 over RCCL, the gather overlapping the next step's synthesis.
-Weak scaling: 128 utterances per GPU.  Synthetic text / styles / weights (no assets offline).
-Prints ONE JSON line on rank 0."""
+`value` is that device-resident rate (the headline, as the task contract defines it); `value_host` beside it is the
+host-to-host rate of _infer's own contract (/root/reference/cpp/helper.cpp:674-682: host text in, host waveform out): text
+frontend -> pinned upload -> synthesis -> 16-bit PCM back in host memory, the copy of batch i overlapping batch i+1.
+--scaling weak (default): 128 utterances per GPU; --scaling strong: 128 utterances in all, 128/N per GPU.
+Synthetic text / styles / weights (no assets offline).  Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -34,8 +37,11 @@ def parse():
     ap.add_argument("--total-step", type=int, default=5)
     ap.add_argument("--speed", type=float, default=1.05)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--cpu-sample", type=int, default=128, help="utterances timed on the CPU oracle (0 = skip); 128 = the whole batch, ~10 s")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="utterances timed on the CPU oracle (0 = skip): 1 warm-up + 3 timed runs, ~15 s at 32")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch utterances per GPU; strong: --batch utterances in all")
+    ap.add_argument("--no-host-loop", action="store_true", help="skip the host-to-host loop (value_host)")
+    ap.add_argument("--no-b1", action="store_true", help="skip the single-utterance record (config C2)")
     return ap.parse_args()
 
 
@@ -68,11 +74,9 @@ def main():
 
     # ---- workload: 128*N utterances, sorted by length and dealt round-robin ---------------------
     arch = default_arch()
-    if args.mixed:
-        texts_all = workload.utterances(args.batch * world, min_words=4, max_words=48, seed=1234)
-    else:
-        texts_all = workload.utterances(args.batch * world, args.words, seed=1234)
-    shards = shard_by_length([len(t) for t in texts_all], world)
+    from supertonic_amd.dist import bench_shards
+    texts_all, shards = bench_shards(args.batch, world, args.scaling, args.mixed, args.words)
+    n_total = len(texts_all)
     mine = shards[rank]
     texts = [texts_all[i] for i in mine]
     up = host.UnicodeProcessor(host.synthetic_indexer())
@@ -157,7 +161,7 @@ def main():
         avg_ms = st["ms"] / max(st["launches"], 1)
         flops_per_launch = st["flops"] / max(st["launches"], 1)
         bytes_per_launch = st["bytes"] / max(st["launches"], 1)
-        is_gemm = "gemm" in dominant or "attention" in dominant
+        is_gemm = "gemm" in dominant or "attention" in dominant or "ffn" in dominant
         if is_gemm:
             peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -167,9 +171,13 @@ def main():
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4))
         roof.update(kernel=dominant, avg_launch_us=round(avg_ms * 1e3, 2), launches_timed=st["launches"],
                     algorithmic_flops_per_launch=flops_per_launch, algorithmic_bytes_per_launch=bytes_per_launch)
-        pmc = _pmc_traffic(dominant)
-        roof["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
-        mu = _pmc_mfma(dominant)
+        pmc, stale = _pmc_traffic(dominant)
+        roof["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc and not stale else None
+        if stale:  # the committed counters were taken on other kernel sources: not this build's traffic
+            roof["profile_stale"] = True
+            roof["profile_stale_note"] = "profiles/pmc_traffic.json was recorded at another source hash (tools/src_hash.py); re-run tools/profile_round.sh"
+            pmc = None
+        mu = None if stale else _pmc_mfma(dominant)
         if mu:
             roof["mfma_util_pmc"] = round(mu["mfma_util"], 4)
             roof["mfma_util_source"] = ("profiles/mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of this kernel in a "
@@ -209,6 +217,11 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat))
 
+    # ---- host-to-host: text frontend -> pinned upload -> synthesis -> 16-bit PCM in host memory, per batch --------------------
+    hostrec = None
+    if not args.no_host_loop:
+        hostrec = host_loop(eng, up, texts, sttl, sdp, durs, mine, args, fence)
+
     audio_per_step_rank = float((durs / np.float32(args.speed)).sum())
     if use_dist:
         t = torch.tensor([audio_per_step_rank], dtype=torch.float64, device=dev)
@@ -218,18 +231,23 @@ def main():
         audio_per_step = audio_per_step_rank
     value = audio_per_step * args.steps / elapsed
 
+    if hostrec and use_dist:  # every rank takes part in the max over ranks
+        t = torch.tensor([hostrec["elapsed"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hostrec["elapsed"] = float(t.item())
     if rank == 0:
         B, L, W = eng.batch_dims()
         out = {
-            "metric": "audio-sec/sec (RTF^-1), 66M model, batch=128 per GPU",
+            "metric": "audio-sec/sec (RTF^-1), 66M model, batch=128 per GPU" if args.scaling == "weak" else "audio-sec/sec (RTF^-1), 66M model, batch=128 in all (strong scaling)",
             "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"C4: batch={args.batch} mixed-length (4..48 words) English utterances per GPU, "
                                     f"{args.total_step} Euler steps, {args.dtype} (BASELINE.json configs[3])") if args.mixed else
-                                   (f"C3: batch={args.batch} {args.words}-word English utterances per GPU, "
+                                   (f"C3: batch={args.batch} {args.words}-word English utterances {'per GPU' if args.scaling == 'weak' else 'in all (' + str(len(texts)) + ' on rank 0)'}, "
                                     f"{args.total_step} Euler steps, {args.dtype} (BASELINE.json configs[2])"),
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "total_step": args.total_step,
+                       "batch_per_gpu": len(texts), "global_batch": n_total, "total_step": args.total_step,
+                       "durations": "forced to n_chars / 15 s before /speed (synthetic weights predict meaningless lengths); the duration predictor still runs, only its device->host read is skipped",
                        "speed": args.speed, "params": eng.param_count, "text_tokens_max": int(ids.shape[1]),
                        "latent_frames_max": L, "audio_sec_per_step": round(audio_per_step, 2),
                        "weights": "synthetic (descriptor include/stn_arch.h, seed 7)",
@@ -238,6 +256,12 @@ def main():
             "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM)",
             "roofline": roof,
         }
+        if hostrec:
+            el_h = hostrec.pop("elapsed")
+            out["value_host"] = round(audio_per_step * args.steps / el_h, 1)
+            out["ms_per_step_host"] = round(el_h / args.steps * 1e3, 3)
+            out["p50_latency_host_ms"] = hostrec.pop("p50")
+            out["host_loop"] = hostrec
         if graph:
             graph["value"] = round(audio_per_step * (1 if world == 1 else 1) / (graph["ms_per_step"] * 1e-3), 1) if world == 1 else None
             graph["note"] = ("same workload as hipGraph replays of the post-duration pipeline; `value` above is the eager timed region "
@@ -252,7 +276,7 @@ def main():
             other = {}
             for k, v in top:
                 ms = v["ms"] / max(v["launches"], 1)
-                if "gemm" in k or "attention" in k:
+                if "gemm" in k or "attention" in k or "ffn" in k:
                     peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
                     a_ = v["flops"] / max(v["launches"], 1) / (ms * 1e-3) / 1e12
                     other[k] = {"bound": "mfma", "achieved": round(a_, 1), "unit": "TFLOP/s", "frac": round(a_ / peak, 4), "avg_us": round(ms * 1e3, 1)}
@@ -278,6 +302,8 @@ def main():
                                         "hbm": {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)},
                                         "mfma": {"achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tfs / peak, 4)},
                                         "note": "event-timed spans of every vo.* launch in one fully profiled step"}
+        if world == 1 and not args.no_b1 and not args.mixed:
+            out["single_utterance"] = single_utterance(eng, arch, up, args)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args)
         sys.stdout.flush()
@@ -289,15 +315,19 @@ def main():
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from an offline `rocprofv3 --pmc` pass of this same command
-    (profiles/pmc_traffic.json, written by tools/pmc_summary.py); None until such a pass exists."""
+    """(entry, stale): HBM bytes per launch of the dominant kernel from an offline `rocprofv3 --pmc` pass of this same command
+    (profiles/pmc_traffic.json, written by tools/pmc_summary.py), and whether that pass was taken on other kernel sources than
+    the tree's (the file records tools/src_hash.py's hash); (None, False) until such a pass exists."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get(kernel)
+            d = json.load(open(p))
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from src_hash import source_sha
+            return d.get(kernel), d.get("_source_sha") != source_sha(ROOT)
         except Exception:
-            return None
-    return None
+            return None, False
+    return None, False
 
 
 def _pmc_mfma(kernel):
@@ -311,21 +341,128 @@ def _pmc_mfma(kernel):
     return None
 
 
+def host_loop(eng, up, texts, sttl, sdp, durs, utt_ids, args, fence):
+    """K batches host-to-host, as _infer's contract has it (/root/reference/cpp/helper.cpp:469-683: strings and host tensors in,
+    a host waveform out): per batch the C++ text frontend (text -> ids, mask), the upload of ids / mask / styles from page-locked
+    host memory, the synthesis, and the 16-bit PCM (what writeWavFile stores, cpp/helper.cpp:986-987) back in page-locked host
+    memory — the device->host copy of batch i runs on a second stream under the upload and synthesis of batch i+1."""
+    from supertonic_amd import binding
+    B = len(texts)
+    langs = ["en"] * B
+    ids0, mask0 = up(texts, langs)
+    p_ids = binding.pinned_array(ids0.shape, np.int64)
+    p_mask = binding.pinned_array(mask0.shape, np.float32)
+    p_ttl = binding.pinned_array(sttl.shape, np.float32)
+    p_dp = binding.pinned_array(sdp.shape, np.float32)
+    p_ttl[...] = sttl
+    p_dp[...] = sdp
+    t_front = [0.0]
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(1)  # the text of batch i+1 is prepared while the GPU runs batch i (the ctypes call drops the GIL)
+
+    def front():
+        t0 = time.perf_counter()
+        r = up(texts, langs)
+        t_front[0] += time.perf_counter() - t0
+        return r
+
+    def one(k, fut=None, more=True):
+        ids, mask = fut.result() if fut is not None else front()
+        p_ids[...] = ids
+        p_mask[...] = mask
+        eng.batch_upload(p_ids, p_mask, p_ttl, p_dp, duration_override=durs, utt_ids=utt_ids)
+        nxt = pool.submit(front) if (fut is not None and more) else None
+        eng.batch_run(args.total_step, args.speed, 1234)
+        eng.fetch_pcm16_begin(k)
+        return nxt
+
+    checksum = 0
+    for i in range(2):  # warm-up of both slots
+        one(i & 1)
+    eng.fetch_pcm16_end(0, copy=False)
+    eng.fetch_pcm16_end(1, copy=False)
+    fence()
+    t_front[0] = 0.0
+    t0 = time.perf_counter()
+    fut = pool.submit(front)
+    for i in range(args.steps):
+        fut = one(i & 1, fut, i + 1 < args.steps)
+        if i:
+            pcm, _ = eng.fetch_pcm16_end((i - 1) & 1, copy=False)
+            checksum ^= int(pcm[0, 0])  # the host owns the waveform here
+    pcm, d = eng.fetch_pcm16_end((args.steps - 1) & 1, copy=False)
+    fence()
+    elapsed = time.perf_counter() - t0
+    pool.shutdown()
+    n_pcm = int(pcm.size)
+    lat = []
+    for _ in range(5):  # one batch alone, nothing to overlap with
+        fence()
+        t1 = time.perf_counter()
+        one(0)
+        eng.fetch_pcm16_end(0, copy=False)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    h2d = int(p_ids.nbytes + p_mask.nbytes + p_ttl.nbytes + p_dp.nbytes + durs.nbytes + 8 * B)
+    return {"elapsed": elapsed, "p50": round(float(np.median(lat)), 3),
+            "text_frontend_ms_per_step": round(t_front[0] / args.steps * 1e3, 3),
+            "pcie_bytes_per_step": {"h2d": h2d, "d2h": n_pcm * 2 + 4 * B},
+            "note": "per batch: text -> ids (C++ frontend), upload from pinned memory, synthesis, int16 PCM into pinned host memory; the "
+                    "device->host copy of batch i and the text frontend of batch i+1 (one worker thread) overlap the synthesis (stn_batch_fetch_pcm16_begin/_end); "
+                    "every batch is tokenised anew; p50_latency_host_ms = one batch alone, nothing overlapped"}
+
+
+def single_utterance(eng_bf16, arch, up, args):
+    """BASELINE.json configs[1] (C2) as a secondary record: the fixed 10-word sentence, batch of one, default steps; p50 / p90 of
+    200 resident-batch syntheses after 20 warm-ups (graph replay from the third call on), fp32 and the bench dtype."""
+    from supertonic_amd import binding, workload
+    text = [workload.C1_SENTENCE]
+    ids, mask = up(text, ["en"])
+    sttl, sdp = workload.synthetic_styles(arch, [0])
+    durs = workload.forced_durations(text)
+    out = {"workload": f"C2: '{text[0]}' ({len(text[0])} chars, {float(durs[0] / args.speed):.2f} s of audio), batch 1, {args.total_step} Euler steps, resident inputs"}
+    for name in ("f32", args.dtype):
+        if name in out:
+            continue
+        eng = eng_bf16 if name == args.dtype else binding.Engine(0, name)
+        if eng is not eng_bf16:
+            eng.load_synthetic(arch, 7)
+        eng.batch_upload(ids, mask, sttl, sdp, duration_override=durs, utt_ids=[0])
+        for _ in range(20):
+            eng.batch_run(args.total_step, args.speed, 1234)
+        eng.sync()
+        lat = []
+        for _ in range(200):
+            t1 = time.perf_counter()
+            eng.batch_run(args.total_step, args.speed, 1234)
+            eng.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        out[name] = {"p50_ms": round(float(np.percentile(lat, 50)), 3), "p90_ms": round(float(np.percentile(lat, 90)), 3),
+                     "audio_sec_per_sec": round(float(durs[0] / args.speed) / (float(np.percentile(lat, 50)) * 1e-3), 1)}
+        if eng is not eng_bf16:
+            eng.close()
+    return out
+
+
 def cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args):
-    """The CPU oracle (plain-C fp32 restatement, OpenMP) timed on a bounded sample of the SAME workload.
-    kind = "port": the reference's ORT-CPU path cannot run here (no ONNX Runtime, no ONNX graphs)."""
+    """The CPU oracle (plain-C fp32 restatement, OpenMP) timed on a bounded sample of the SAME workload: 1 warm-up + 3 timed
+    runs, the median reported.  kind = "port": the reference's ORT-CPU path cannot run here (no ONNX
+    Runtime, no ONNX graphs)."""
     from oracle import neural_ref
     n = min(args.cpu_sample, len(texts))
     lens = mask[:n].sum(axis=(1, 2)).astype(int)
     lt = int(lens.max())
     ref = neural_ref.RefModel(arch, 7)
-    t0 = time.perf_counter()
-    _, d = ref.synthesize(ids[:n, :lt], mask[:n, :, :lt], sttl[:n], sdp[:n], args.total_step, args.speed,
-                          lambda B, D, L: neural_ref.randn(1234, B, D, L), duration_override=durs[:n])
-    dt = time.perf_counter() - t0
+    times, d = [], None
+    for run in range(4):
+        t0 = time.perf_counter()
+        _, d = ref.synthesize(ids[:n, :lt], mask[:n, :, :lt], sttl[:n], sdp[:n], args.total_step, args.speed,
+                              lambda B, D, L: neural_ref.randn(1234, B, D, L), duration_override=durs[:n])
+        if run:
+            times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     return {"value": round(float(d.sum()) / dt, 2), "unit": "audio-sec/sec", "cores": neural_ref.threads(), "kind": "port",
-            "sample": f"first {n} utterances of the same batch as one padded batch, fp32, {args.total_step} Euler steps, "
-                      f"{dt:.1f} s wall on {neural_ref.threads()} OpenMP threads (oracle/stn_ref.c)"}
+            "sample": f"first {n} utterances of the same batch as one padded batch, fp32, {args.total_step} Euler steps; 1 warm-up + 3 timed "
+                      f"runs, median {dt:.1f} s wall ({min(times):.1f}-{max(times):.1f}) on {neural_ref.threads()} OpenMP threads (oracle/stn_ref.c)"}
 
 
 if __name__ == "__main__":

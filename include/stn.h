@@ -134,6 +134,16 @@ int stn_batch_fetch(stn_handle* h, float* wav, size_t wav_capacity_floats, float
 /* same, as 16-bit PCM converted on the GPU exactly as writeWavFile does (clamp to [-1,1], *32767, truncation;
  * cpp/helper.cpp:986-987): half the device->host bytes */
 int stn_batch_fetch_pcm16(stn_handle* h, int16_t* pcm, size_t capacity_samples, float* duration);
+/* the same, pipelined over two slots: _begin converts to PCM on the GPU and starts the device->host copy on a second stream,
+ * so that the copy of batch i overlaps stn_batch_upload / stn_batch_run of batch i+1; _end waits for the slot's copy and hands
+ * out the handle's pinned host buffer ([B, W] int16, valid until the slot's next _begin) with the batch's durations.  This is
+ * the host-to-host path of _infer's contract (host inputs in, host waveform out: cpp/helper.cpp:674-682) at full overlap. */
+int stn_batch_fetch_pcm16_begin(stn_handle* h, int slot /* 0 or 1 */);
+int stn_batch_fetch_pcm16_end(stn_handle* h, int slot, const int16_t** pcm, size_t* n_samples, float* duration_or_null);
+/* page-locked host memory for the caller's input buffers (ids, masks, styles): uploads from it are asynchronous DMA instead of a
+ * staged copy.  NULL on failure. */
+void* stn_host_alloc_pinned(size_t bytes);
+void stn_host_free_pinned(void* p);
 int stn_batch_fetch_latent(stn_handle* h, float* latent /*[B,D,L]*/);
 /* device pointer of the finished waveform [B, L*cs] float32 (valid until the next upload/run) */
 int stn_batch_wav_device_ptr(const stn_handle* h, void** ptr);

@@ -76,6 +76,11 @@ def load():
     L.stn_batch_fetch.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
     L.stn_batch_fetch_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.stn_batch_fetch_pcm16_begin.argtypes = [vp, ci]
+    L.stn_batch_fetch_pcm16_end.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), vp]
+    L.stn_host_alloc_pinned.restype = vp
+    L.stn_host_alloc_pinned.argtypes = [ctypes.c_size_t]
+    L.stn_host_free_pinned.argtypes = [vp]
     L.stn_batch_wav_device_ptr.argtypes = [vp, ctypes.POINTER(vp)]
     L.stn_sync.argtypes = [vp]
     L.stn_set_stream.argtypes = [vp, vp]
@@ -247,6 +252,22 @@ class Engine:
         """False: the reference's batched vocoder (padding decoded as zero latent). True: every utterance ends at its own length."""
         self._ck(self._lib.stn_set_vocoder_mode(self._h, int(bool(length_aware))))
 
+    def fetch_pcm16_begin(self, slot):
+        """Start the PCM conversion + device->host copy of the finished batch on `slot` (0/1); returns at once."""
+        self._ck(self._lib.stn_batch_fetch_pcm16_begin(self._h, int(slot)))
+
+    def fetch_pcm16_end(self, slot, copy=True):
+        """Wait for the slot's copy -> (pcm [B, W] int16, duration [B]).  copy=False returns a view of the handle's pinned buffer
+        (valid until the slot's next fetch_pcm16_begin)."""
+        B, L, W = self.batch_dims()
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        dur = np.empty(B, np.float32)
+        self._ck(self._lib.stn_batch_fetch_pcm16_end(self._h, int(slot), ctypes.byref(ptr), ctypes.byref(n), dur.ctypes.data))
+        arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int16)), shape=(n.value,))
+        rows = n.value // max(dur.size, 1)
+        arr = arr.reshape(dur.size, rows)
+        return (arr.copy() if copy else arr), dur
+
     @property
     def graph_replays(self):
         return self._lib.stn_graph_replays(self._h)
@@ -402,3 +423,19 @@ class Engine:
         _l, lp = _opt(length, np.int32)
         self._ck(self._lib.stn_op_randn(self._h, seed, B, D, L, up, lp, out))
         return out
+
+
+def pinned_array(shape, dtype):
+    """A numpy array on page-locked host memory (stn_host_alloc_pinned): uploads from it are asynchronous DMA.  The memory is
+    released when the array (and every view of it) is gone."""
+    L = load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = L.stn_host_alloc_pinned(n)
+    if not p:
+        raise MemoryError("stn_host_alloc_pinned failed")
+    buf = (ctypes.c_char * n).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+    import weakref
+    weakref.finalize(buf, L.stn_host_free_pinned, ctypes.c_void_p(p))
+    return arr

@@ -267,6 +267,17 @@ int stn_batch_fetch(stn_handle* h, float* wav, size_t cap, float* duration) {
 int stn_batch_fetch_pcm16(stn_handle* h, int16_t* pcm, size_t cap, float* duration) {
     STN_TRY(h, { need(pcm && h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_pcm16(pcm, cap, duration); })
 }
+int stn_batch_fetch_pcm16_begin(stn_handle* h, int slot) {
+    STN_TRY(h, { need(h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_pcm16_begin(slot); })
+}
+int stn_batch_fetch_pcm16_end(stn_handle* h, int slot, const int16_t** pcm, size_t* n_samples, float* duration) {
+    STN_TRY(h, { h->eng->batch_fetch_pcm16_end(slot, pcm, n_samples, duration); })
+}
+void* stn_host_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void stn_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 int stn_batch_fetch_latent(stn_handle* h, float* latent) {
     STN_TRY(h, { need(latent && h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_latent(latent); })
 }

@@ -106,6 +106,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     s_ = own_s_;
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
+    if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
     if (const char* p = getenv("STN_XATTN")) fused_xattn_ = atoi(p) != 0;  // A/B switch: one launch per cross-attention block
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
@@ -152,6 +153,14 @@ Engine::~Engine() {
     if (pin_llen_) (void)hipHostFree(pin_llen_);
     if (pin_seed_) (void)hipHostFree(pin_seed_);
     if (seed_dev_) (void)hipFree(seed_dev_);
+    for (auto& f : fetch_) {
+        if (f.busy && f.done) (void)hipEventSynchronize(f.done);
+        if (f.dev) (void)hipFree(f.dev);
+        if (f.pin) (void)hipHostFree(f.pin);
+        if (f.ready) (void)hipEventDestroy(f.ready);
+        if (f.done) (void)hipEventDestroy(f.done);
+    }
+    if (copy_s_) (void)hipStreamDestroy(copy_s_);
     if (own_s_) (void)hipStreamDestroy(own_s_);
 }
 
@@ -500,7 +509,10 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     // K4: pw1 -> GELU -> pw2 -> layer scale + residual in one launch, the hidden activation never leaves the registers
     const int stage_bit = stage_[0] == 'v' && stage_[1] == 'o' ? 1 : (stage_[0] == 'v' ? 2 : 4);
     const auto fw = ffn_w_.find(p.pw1.w.as(dt_));
-    if ((fused_ffn_ & stage_bit) && fw != ffn_w_.end() && ffn_fused_supported(dt_, C, hid) && M * C * 2 < 0x7FFFFFFFll) {
+    // ... where it pays: a workgroup streams both weight matrices whatever its share of the rows, so below ~half a chip of
+    // 128-row workgroups the two tiled launches win (tools/ffn_bench.py sweep, C = 512: 16384 rows 108 vs 107 us, 20480 rows
+    // 116 vs 141 us, 294 rows = one utterance 102 vs 29 us)
+    if ((fused_ffn_ & stage_bit) && M >= ffn_min_rows_ && fw != ffn_w_.end() && ffn_fused_supported(dt_, C, hid) && M * C * 2 < 0x7FFFFFFFll) {
         FfnArgs fa;
         fa.xn = xn; fa.ldx = C; fa.wseq = fw->second.wseq; fa.b1 = p.pw1.b; fa.b2 = p.pw2.b; fa.gamma = p.gamma;
         fa.x = x; fa.ldo = C; fa.M = (int)M; fa.I = hid; fa.rowvec = rowvec; fa.rv_ld = rv_ld;
@@ -1327,6 +1339,43 @@ void Engine::batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration) {
     STN_HIP(hipMemcpyAsync(pcm, b.pcm, nw * 2, hipMemcpyDeviceToHost, s_));
     sync();
     if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
+}
+void Engine::batch_fetch_pcm16_begin(int slot) {
+    STN_HIP(hipSetDevice(device_));
+    if (slot < 0 || slot > 1) throw std::invalid_argument("fetch slot must be 0 or 1");
+    Batch& b = bt_;
+    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
+    const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
+    FetchSlot& f = fetch_[slot];
+    if (!copy_s_) STN_HIP(hipStreamCreateWithFlags(&copy_s_, hipStreamNonBlocking));
+    if (!f.ready) { STN_HIP(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming)); STN_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming)); }
+    if (f.busy) STN_HIP(hipEventSynchronize(f.done));  // the slot's previous copy (two batches ago) must be out before it is refilled
+    if (nw > f.cap) {
+        if (f.dev) (void)hipFree(f.dev);
+        if (f.pin) (void)hipHostFree(f.pin);
+        f.dev = nullptr; f.pin = nullptr;
+        const size_t cap = nw + nw / 4;
+        STN_HIP(hipMalloc(reinterpret_cast<void**>(&f.dev), cap * sizeof(int16_t)));
+        STN_HIP(hipHostMalloc(reinterpret_cast<void**>(&f.pin), cap * sizeof(int16_t), hipHostMallocDefault));
+        f.cap = cap;
+    }
+    launch_f32_to_pcm16(s_, b.wav, (int64_t)b.B, (int)(nw / (size_t)b.B), f.dev, (int64_t)(nw / (size_t)b.B));
+    STN_HIP(hipEventRecord(f.ready, s_));
+    STN_HIP(hipStreamWaitEvent(copy_s_, f.ready, 0));
+    STN_HIP(hipMemcpyAsync(f.pin, f.dev, nw * sizeof(int16_t), hipMemcpyDeviceToHost, copy_s_));
+    STN_HIP(hipEventRecord(f.done, copy_s_));
+    f.n = nw;
+    f.dur = reported_dur_;
+    f.busy = true;
+}
+void Engine::batch_fetch_pcm16_end(int slot, const int16_t** pcm, size_t* n, float* duration) {
+    if (slot < 0 || slot > 1) throw std::invalid_argument("fetch slot must be 0 or 1");
+    FetchSlot& f = fetch_[slot];
+    if (!f.busy) throw std::runtime_error("no fetch in flight on this slot");
+    STN_HIP(hipEventSynchronize(f.done));
+    if (pcm) *pcm = f.pin;
+    if (n) *n = f.n;
+    if (duration) std::copy(f.dur.begin(), f.dur.end(), duration);
 }
 void Engine::batch_copy_wav_device(float* dst, int64_t dst_stride) {
     Batch& b = bt_;

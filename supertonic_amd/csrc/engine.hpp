@@ -175,6 +175,11 @@ class Engine {
     void batch_fetch(float* wav, size_t wav_capacity, float* duration);
     // waveform as 16-bit PCM (clamp, *32767, truncate: cpp/helper.cpp:986-987) converted on the GPU: half the D2H bytes
     void batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration);
+    // The same, pipelined: _begin converts into the device slot and starts its device->host copy on a second stream (the next
+    // stn_batch_upload / stn_batch_run proceed meanwhile: the copy of batch i overlaps the synthesis of batch i+1); _end waits
+    // for that copy and hands out the slot's pinned host buffer (valid until the slot's next _begin).  Two slots.
+    void batch_fetch_pcm16_begin(int slot);
+    void batch_fetch_pcm16_end(int slot, const int16_t** pcm, size_t* n, float* duration);
     void batch_fetch_latent(float* latent);  // final denoised latent [B,D,L] (tests)
     // device->device: wav rows [B][W] into dst rows of stride dst_stride floats (>= W), on the engine's stream
     void batch_copy_wav_device(float* dst, int64_t dst_stride);
@@ -278,6 +283,7 @@ class Engine {
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
     bool nt_hints_ = true;
+    int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int fused_ffn_ = 1;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
     bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip): correct but, as
                                 // measured, slower than the four-launch form at batch 128 -> opt-in: STN_XATTN=1
@@ -292,6 +298,9 @@ class Engine {
     bool pin_valid_ = false;
     unsigned long long* seed_dev_ = nullptr;
     int final_xt_ = 0;
+    struct FetchSlot { int16_t* dev = nullptr; int16_t* pin = nullptr; size_t cap = 0, n = 0; hipEvent_t ready = nullptr, done = nullptr; bool busy = false; std::vector<float> dur; };
+    FetchSlot fetch_[2];
+    hipStream_t copy_s_ = nullptr;
     bool prof_on_ = false;
     std::vector<ProfSpan> spans_;
     std::vector<hipEvent_t> ev_pool_;

@@ -11,6 +11,23 @@ def shard_by_length(lengths, world_size):
     return [order[r::world_size] for r in range(world_size)]
 
 
+def bench_shards(batch, world_size, scaling="weak", mixed=False, words=10, seed=1234):
+    """The benchmark's utterances and their deal over the ranks (bench.py).  weak: `batch` utterances per rank (batch * world in
+    all); strong: `batch` utterances in all, batch / world per rank (north_star: "a 128-utterance batch at 1, 2, 4 and 8 MI355X").
+    Returns (texts_all, shards): shards[r] = indices of rank r's utterances, length-sorted and dealt round-robin."""
+    from . import workload
+    if scaling not in ("weak", "strong"):
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    n_total = batch * world_size if scaling == "weak" else batch
+    if n_total < world_size:
+        raise ValueError(f"strong scaling needs at least one utterance per rank ({n_total} < {world_size})")
+    if mixed:
+        texts = workload.utterances(n_total, min_words=4, max_words=48, seed=seed)
+    else:
+        texts = workload.utterances(n_total, words, seed=seed)
+    return texts, shard_by_length([len(t) for t in texts], world_size)
+
+
 class GatherPlan:
     """Shapes of every rank's [B, W] waveform block, exchanged ONCE (tiny all-gather + host read); afterwards a gather is a
     single collective per batch with no host synchronisation.

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from supertonic_amd import workload
-from supertonic_amd.dist import GatherPlan, gather_waveforms, shard_by_length
+from supertonic_amd.dist import GatherPlan, bench_shards, gather_waveforms, shard_by_length
 
 
 def test_shard_by_length_balances_and_partitions():
@@ -23,6 +23,23 @@ def test_shard_by_length_balances_and_partitions():
     assert tot.max() / tot.min() < 1.02  # balanced total work
     # length-sorted dealing keeps per-rank padding close to the global sorted order
     assert all(np.all(np.diff(lens[s]) <= 0) for s in shards)
+
+
+def test_bench_shards_weak_and_strong():
+    """bench.py --scaling weak|strong: 128 utterances per rank, or 128 in all (north_star's 128-utterance batch at 1/2/4/8 GPUs)."""
+    for world in (1, 2, 4, 8):
+        tw, sw = bench_shards(128, world, "weak")
+        ts, ss = bench_shards(128, world, "strong")
+        assert len(tw) == 128 * world and all(len(x) == 128 for x in sw)
+        assert len(ts) == 128 and all(len(x) == 128 // world for x in ss)
+        for texts, sh in ((tw, sw), (ts, ss)):
+            assert np.array_equal(np.sort(np.concatenate(sh)), np.arange(len(texts)))
+            tot = np.array([sum(len(texts[i]) for i in x) for x in sh])
+            assert tot.max() / tot.min() < 1.06
+    assert bench_shards(128, 1, "weak")[0] == bench_shards(128, 1, "strong")[0]  # one GPU: the same job either way
+    import pytest
+    with pytest.raises(ValueError):
+        bench_shards(4, 8, "strong")
 
 
 def _free_port():
@@ -45,6 +62,13 @@ def _worker(rank, world, port, q):
 
 def _worker_body(rank, world, q):
     if True:
+        # strong scaling as bench.py does it: every rank derives the same deal and takes its own share
+        texts, shards = bench_shards(128, world, "strong")
+        got = [None] * world
+        dist.all_gather_object(got, [int(i) for i in shards[rank]])
+        if sorted(sum(got, [])) != list(range(128)) or any(len(g) != 128 // world for g in got):
+            q.put("strong-scaling shards do not partition the batch")
+            return
         B, W = (3, 40) if rank == 0 else (2, 56)  # ragged: row counts and lengths differ per rank
         wav = torch.arange(B * W, dtype=torch.float32).reshape(B, W) + 1000 * rank
         dur = torch.arange(B, dtype=torch.float32) + 10 * rank

@@ -34,3 +34,24 @@ def test_bench_json_line_contract():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
     assert d["value"] / c["value"] > 50  # a GPU engine that is not far ahead of 16 host threads is broken
+    assert "1 warm-up + 3 timed" in c["sample"]
+    # host-to-host rate beside the device-resident one (the contract of _infer's return, cpp/helper.cpp:674-682)
+    for k in ("value_host", "ms_per_step_host", "p50_latency_host_ms", "host_loop"):
+        assert k in d, k
+    assert 0 < d["value_host"] <= d["value"] * 1.02 and d["ms_per_step_host"] >= d["ms_per_step"] * 0.98
+    assert abs(d["value_host"] - d["config"]["audio_sec_per_step"] / (d["ms_per_step_host"] * 1e-3)) / d["value_host"] < 1e-3
+    pc = d["host_loop"]["pcie_bytes_per_step"]
+    assert pc["d2h"] > 10e6 and pc["h2d"] > 1e6 and d["p50_latency_host_ms"] >= d["ms_per_step_host"] * 0.9
+    assert "forced" in d["config"]["durations"]
+    su = d["single_utterance"]
+    assert su["f32"]["p50_ms"] > 0 and su["bf16"]["p50_ms"] > 0 and su["bf16"]["p50_ms"] < su["f32"]["p50_ms"]
+    if r.get("profile_stale"):
+        assert r["traffic"] is None
+
+
+def test_bench_strong_scaling_flag():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--scaling", "strong",
+                        "--no-host-loop", "--no-b1", "--no-profile"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 128 and d["config"]["batch_per_gpu"] == 128

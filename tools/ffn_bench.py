@@ -1,6 +1,6 @@
 """K4 against the two launches it replaces, on the model's shapes (stn_op_ffn_bench): device-resident random operands,
 HIP-event timing over `iters` calls, plus the fused kernel's in-kernel phase stamps (shader-clock cycles per workgroup).
-Usage (on a GPU box): python tools/ffn_bench.py [iters]"""
+Usage (on a GPU box): python tools/ffn_bench.py [iters] [sweep]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from supertonic_amd import binding
@@ -8,7 +8,9 @@ from supertonic_amd import binding
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 eng = binding.Engine(0, "bf16")
 shapes = [("vo  (C3 dense)", 59904, 512, 2048), ("vo  (half)", 29952, 512, 2048), ("ve  (C3 packed)", 7436, 384, 1536),
-          ("ve  (padded)", 9984, 384, 1536), ("ve  (2 batches)", 14872, 384, 1536)]
+          ("ve  (padded)", 9984, 384, 1536), ("ve  (8 batches)", 59488, 384, 1536)]
+if len(sys.argv) > 2:  # where the fused kernel starts to pay: rows sweep at the vocoder's width
+    shapes = [(f"vo M={m}", m, 512, 2048) for m in (294, 2048, 4096, 8192, 12288, 16384, 20480, 24576, 28672, 32768, 36864, 49152)]
 for name, M, C, I in shapes:
     # interleave the two arms (rule: A/B in one process, alternating)
     f, u = [], []
