@@ -163,6 +163,9 @@ int stn_profile_enable(stn_handle* h, int on);
 int stn_profile_reset(stn_handle* h);
 /* time only one kernel family ("stage.kernel", e.g. "vo.gemm_pw1_gelu"); NULL or "" = all families */
 int stn_profile_filter(stn_handle* h, const char* family_or_null);
+/* time only every n-th matching launch (n >= 1): a launch that carries events does not overlap its neighbours on the stream
+   (~4 us each), so a timed region samples its dominant family instead of fencing every launch of it */
+int stn_profile_sample(stn_handle* h, int every);
 /* number of kernel families seen; then per index: name, total ms, launches, algorithmic flops and bytes */
 int stn_profile_count(stn_handle* h);
 int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,

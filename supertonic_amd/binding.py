@@ -87,6 +87,7 @@ def load():
     L.stn_batch_copy_wav_device.argtypes = [vp, vp, ctypes.c_int64]
     L.stn_batch_copy_pcm16_device.argtypes = [vp, vp, ctypes.c_int64]
     L.stn_profile_filter.argtypes = [vp, ctypes.c_char_p]
+    L.stn_profile_sample.argtypes = [vp, ci]
     L.stn_profile_enable.argtypes = [vp, ci]
     L.stn_profile_reset.argtypes = [vp]
     L.stn_profile_count.argtypes = [vp]
@@ -335,6 +336,9 @@ class Engine:
 
     def profile_filter(self, family=None):
         self._ck(self._lib.stn_profile_filter(self._h, family.encode() if family else None))
+
+    def profile_sample(self, every=1):
+        self._ck(self._lib.stn_profile_sample(self._h, int(every)))
 
     def profile_reset(self):
         self._ck(self._lib.stn_profile_reset(self._h))

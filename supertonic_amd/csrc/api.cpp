@@ -296,6 +296,7 @@ int stn_batch_copy_wav_device(stn_handle* h, void* dst, int64_t stride) {
 }
 
 int stn_profile_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->profile_enable(on != 0); }) }
+int stn_profile_sample(stn_handle* h, int every) { STN_TRY(h, { h->eng->profile_sample(every); }) }
 int stn_profile_filter(stn_handle* h, const char* fam) { STN_TRY(h, { h->eng->profile_filter(fam ? fam : ""); }) }
 int stn_profile_reset(stn_handle* h) { STN_TRY(h, { h->eng->profile_reset(); h->prof.clear(); }) }
 int stn_profile_count(stn_handle* h) {

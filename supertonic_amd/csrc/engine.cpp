@@ -414,6 +414,7 @@ void Engine::prof_begin(const char* tag, double flops, double bytes) {
     if (!prof_on_ || spans_.size() > 200000) return;
     std::string full = std::string(stage_) + "." + tag;
     if (!prof_filter_.empty() && full != prof_filter_) return;
+    if (prof_every_ > 1 && (prof_seen_++ % prof_every_) != 0) return;  // sampled: a launch that carries events does not overlap its neighbours
     ProfSpan sp;
     sp.tag = std::move(full);
     sp.flops = flops;

@@ -188,6 +188,7 @@ class Engine {
 
     // ---- profiling (hipEvent pairs around launches of one kernel family, on this stream) ----------------
     void profile_enable(bool on) { if (on != prof_on_) profile_reset(); prof_on_ = on; }
+    void profile_sample(int every) { prof_every_ = every < 1 ? 1 : every; prof_seen_ = 0; }  // time every n-th matching launch only
     void profile_filter(const std::string& family) { if (family != prof_filter_) profile_reset(); prof_filter_ = family; }  // "" = every family
     void profile_reset();
     std::vector<std::pair<std::string, KernelStat>> profile_collect();
@@ -247,6 +248,8 @@ class Engine {
     hipStream_t s_ = nullptr, own_s_ = nullptr;
     const char* stage_ = "";
     std::string prof_filter_;
+    int prof_every_ = 1;
+    uint64_t prof_seen_ = 0;
     bool prof_active_ = false;
     stn_arch a_{};
     bool loaded_ = false;
