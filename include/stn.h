@@ -56,14 +56,21 @@ int stn_create(const stn_config* cfg, stn_handle** out);
 int stn_destroy(stn_handle* h);
 /* message of the last failure on this handle (or of the last failed stn_create when h == NULL) */
 const char* stn_last_error(const stn_handle* h);
-/* The reference's asset directory (cpp/helper.cpp:784-823): tts.json + unicode_indexer.json + the four .onnx graphs.
- * tts.json fills the descriptor; the weights are the graphs' INITIALIZERS, read by a built-in protobuf reader and bound to
- * the engine's tensors through `<onnx_dir>/stn_weight_map.json`
+/* The reference's asset directory (cpp/helper.cpp:784-823): tts.json + unicode_indexer.json + the four .onnx graphs, nothing else.
+ * tts.json gives the descriptor's config fields; the graphs are read by a built-in protobuf reader and their NODES are walked in
+ * graph order: the nodes that carry weights (depthwise Conv, pointwise Conv / MatMul+Add / Gemm, LayerNormalization, layer-scale
+ * Mul, Gather) are parsed against the engine's layout (embedding / ConvNeXt blocks / attention blocks / projections), which yields
+ * the rest of the descriptor (widths, depths, kernel sizes, dilations, head counts from the Reshape constants) and binds every
+ * initializer to its canonical tensor by position and role — never by name (csrc/host/graph_bind.hpp; stn_bind_graphs in
+ * stn_host.h shows the result without a device).  Graph input/output names must be the ones the hosts use (cpp/helper.cpp:512-513,
+ * 545-546, 620-623, 663-664); tts.json must agree with the shapes.  A graph that is not this layout fails with the first node that
+ * does not fit, what the layout needs there, and the descriptor derived so far.
+ * Optional `<onnx_dir>/stn_weight_map.json` overrides the walk with an explicit table
  *   {"arch": {<stn_arch field>: int, ...}, "tensors": {"<engine tensor>": {"file": "vocoder.onnx", "name": "<initializer>",
- *    "transpose": false}, ...}}
- * (the real initializer names cannot be known offline, so the manifest is data supplied with the assets).
- * STN_ERR_IO: a file is missing/unreadable/malformed ("Failed to open ..." as cpp/helper.cpp:805); STN_ERR_UNSUPPORTED: graphs
- * present but no manifest (the message lists what each graph contains). */
+ *    "transpose": false}, ...}}   ("transpose" may be omitted: it is inferred from the stored dims, which are checked either way).
+ * STN_ERR_IO: a file is missing/unreadable/malformed ("Failed to open ..." as cpp/helper.cpp:805) or does not bind;
+ * STN_ERR_INVALID: the derived descriptor is outside what the kernels support (message names the field).
+ * After a successful manifest-less load stn_last_error holds notes on what the graphs did not state (e.g. head counts). */
 int stn_load_dir(stn_handle* h, const char* onnx_dir);
 /* '\n'-separated names of every canonical tensor the descriptor implies (what a manifest must map); returns bytes needed */
 int stn_tensor_names(stn_handle* h, const stn_arch* arch, char* out, size_t cap);

@@ -41,6 +41,11 @@ int64_t stn_sanitize_filename(const char* text, int max_len, char* out, size_t c
 /* 44-byte RIFF header + int16 PCM; returns bytes needed (44 + 2n) */
 /* JSON summary of an .onnx file: ir_version, graph inputs/outputs, op histogram, initializers (name, dtype, dims) */
 int64_t stn_onnx_summary(const char* path, char* out, size_t cap);
+/* What stn_load_dir binds when the directory has no stn_weight_map.json, without a device: the descriptor derived from the four
+   graphs' weighted nodes (+ tts.json) and, per canonical tensor, the initializer it was bound to — JSON {"arch": {..},
+   "tensors": {name: {"from": "...", "transpose": bool, "zeros": bool}}, "notes": "..."}.  Fails (STN_ERR_IO, stn_host_last_error) with
+   the first node that does not fit the layout.  Stands in for Ort::Session's own graph loading, cpp/helper.cpp:784-795. */
+int64_t stn_bind_graphs(const char* onnx_dir, char* out, size_t cap);
 
 int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap);
 int stn_write_wav(const char* path, const float* audio, size_t n, int sample_rate);

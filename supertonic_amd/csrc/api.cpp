@@ -8,6 +8,7 @@
 
 #include "engine.hpp"
 #include "host/json_min.hpp"
+#include "host/graph_bind.hpp"
 #include "host/onnx_reader.hpp"
 
 #include <map>
@@ -101,11 +102,9 @@ const std::map<std::string, int32_t stn_arch::*>& arch_fields() {
 }  // namespace
 }  // extern "C++"
 
-// Asset directory of the reference (cpp/helper.cpp:784-823): tts.json + unicode_indexer.json + four .onnx graphs, plus
-// `stn_weight_map.json`, a manifest written by whoever holds the real assets:
-//   {"arch": {"ve_dim": 384, ...},                       optional descriptor overrides ("vo_dilations": [..] too)
-//    "tensors": {"vo.blk0.pw1.w": {"file": "vocoder.onnx", "name": "<initializer name>", "transpose": false}, ...}}
-// Every canonical tensor of the descriptor must be mapped; "transpose": true for MatMul weights stored [K][N].
+// Asset directory of the reference (cpp/helper.cpp:784-823): tts.json + unicode_indexer.json + four .onnx graphs.  Without a
+// manifest the graphs' nodes are walked and bound to the canonical tensor list (host/graph_bind.hpp); an optional
+// `stn_weight_map.json` names the initializers explicitly instead (include/stn.h).
 int stn_load_dir(stn_handle* h, const char* onnx_dir) {
     if (!h) return STN_ERR_INVALID;
     if (!onnx_dir) { h->err = "onnx_dir is null"; return STN_ERR_INVALID; }
@@ -118,39 +117,25 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
     }
     try {
         using stn::json::Value;
-        stn_arch a;
-        stn_arch_default(&a);
-        const Value cfg = stn::json::parse(slurp_text(dir + "/tts.json"));
-        // the four fields every host reads (cpp/helper.cpp:811-815) + the style/projection dims of go/helper.go:45-78 when present
-        a.sample_rate = cfg.at("ae").at("sample_rate").as_int();
-        a.base_chunk_size = cfg.at("ae").at("base_chunk_size").as_int();
-        a.chunk_compress_factor = cfg.at("ttl").at("chunk_compress_factor").as_int();
-        a.latent_dim = cfg.at("ttl").at("latent_dim").as_int();
-        auto opt = [](const Value& v, std::initializer_list<const char*> path, int32_t& dst) {
-            const Value* cur = &v;
-            for (const char* k : path) { if (!cur->is_object() || !cur->has(k)) return; cur = &cur->at(k); }
-            if (cur->type == Value::Number) dst = (int32_t)cur->num;
-        };
-        opt(cfg, {"ttl", "style_encoder", "style_token_layer", "n_style"}, a.n_style_ttl);
-        opt(cfg, {"ttl", "style_encoder", "style_token_layer", "style_value_dim"}, a.d_style_ttl);
-        opt(cfg, {"ttl", "text_encoder", "proj_out", "odim"}, a.te_out_dim);
-        opt(cfg, {"dp", "style_encoder", "style_token_layer", "n_style"}, a.n_style_dp);
-        opt(cfg, {"dp", "style_encoder", "style_token_layer", "style_value_dim"}, a.d_style_dp);
+        stn_arch a = stn::graphbind::arch_from_config(dir + "/tts.json");
 
         const std::string man_path = dir + "/stn_weight_map.json";
         std::map<std::string, stn::onnx::Model> models;
         static const char* graphs[] = {"duration_predictor.onnx", "text_encoder.onnx", "vector_estimator.onnx", "vocoder.onnx"};
+        for (const char* g : graphs) models.emplace(g, stn::onnx::parse_file(dir + "/" + g));
+        stn::graphbind::check_all_io_names(models.at(graphs[0]), models.at(graphs[1]), models.at(graphs[2]), models.at(graphs[3]));
         {
             std::ifstream probe(man_path);
             if (!probe.is_open()) {
-                std::ostringstream msg;
-                msg << "no weight manifest (" << man_path << "): the graphs' initializer names cannot be known offline;";
-                for (const char* g : graphs) {
-                    const stn::onnx::Model m = stn::onnx::parse_file(dir + "/" + g);
-                    msg << " " << g << ": " << m.initializers.size() << " initializers, " << m.nodes.size() << " nodes;";
-                }
-                h->err = msg.str();
-                return STN_ERR_UNSUPPORTED;
+                // no manifest: recognise the layout in the graphs themselves (host/graph_bind.hpp)
+                const stn::graphbind::Result gb = stn::graphbind::bind(a, models.at(graphs[0]), models.at(graphs[1]), models.at(graphs[2]), models.at(graphs[3]));
+                h->eng->load_tensors(gb.arch, [&](const std::string& name, int rows, int cols) {
+                    auto it = gb.tensors.find(name);
+                    if (it == gb.tensors.end()) throw std::runtime_error("graph binding: no initializer was bound to tensor \"" + name + "\"");
+                    return stn::graphbind::fetch(it->second, name, rows, cols);
+                });
+                h->err = gb.notes;  // readable through stn_last_error after a successful load
+                return STN_OK;
             }
         }
         const Value man = stn::json::parse(slurp_text(man_path));
@@ -165,7 +150,6 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
                 a.*(it->second) = kv.second.as_int();
             }
         }
-        for (const char* g : graphs) models.emplace(g, stn::onnx::parse_file(dir + "/" + g));
         const Value& tmap = man.at("tensors");
         h->eng->load_tensors(a, [&](const std::string& name, int rows, int cols) {
             if (!tmap.has(name)) throw std::runtime_error("manifest: no entry for tensor \"" + name + "\"");
@@ -179,7 +163,21 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
             if (v.size() != (size_t)rows * cols)
                 throw std::runtime_error(name + ": initializer " + iname + " has " + std::to_string(v.size()) + " elements, descriptor wants " +
                                          std::to_string(rows) + "x" + std::to_string(cols));
-            if (ent.has("transpose") && ent.at("transpose").boolean) {  // stored [cols][rows] -> canonical [rows][cols]
+            // stored dims (1s dropped) against the canonical [rows][cols]: "transpose" may be stated; otherwise it is inferred when
+            // the dims are unambiguous ([cols][rows] with rows != cols), and dims that are neither orientation are an error
+            std::vector<int64_t> d;
+            for (int64_t x : t->dims) if (x != 1) d.push_back(x);
+            bool tr = ent.has("transpose") && ent.at("transpose").boolean;
+            if (d.size() == 2 && rows > 1 && cols > 1) {
+                const bool as_is = d[0] == rows && d[1] == cols, flipped = d[0] == cols && d[1] == rows;
+                if (!as_is && !flipped)
+                    throw std::runtime_error(name + ": initializer " + iname + " is stored [" + std::to_string(d[0]) + "][" + std::to_string(d[1]) +
+                                             "], neither [" + std::to_string(rows) + "][" + std::to_string(cols) + "] nor its transpose");
+                if (!ent.has("transpose")) tr = flipped && !as_is;
+                else if (tr && !flipped) throw std::runtime_error(name + ": manifest says \"transpose\" but initializer " + iname + " is not stored [" + std::to_string(cols) + "][" + std::to_string(rows) + "]");
+                else if (!tr && !as_is) throw std::runtime_error(name + ": initializer " + iname + " is stored transposed ([" + std::to_string(d[0]) + "][" + std::to_string(d[1]) + "]); the manifest says \"transpose\": false");
+            }
+            if (tr) {  // stored [cols][rows] -> canonical [rows][cols]
                 std::vector<float> w(v.size());
                 for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) w[(size_t)r * cols + c] = v[(size_t)c * rows + r];
                 v.swap(w);
@@ -187,6 +185,9 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
             return v;
         });
         return STN_OK;
+    } catch (const std::invalid_argument& e) {  // the descriptor check of Engine::load_weights
+        h->err = e.what();
+        return STN_ERR_INVALID;
     } catch (const std::exception& e) {
         h->err = e.what();
         return h->err.rfind("HIP error", 0) == 0 ? STN_ERR_DEVICE : STN_ERR_IO;

@@ -1,0 +1,486 @@
+#include "graph_bind.hpp"
+
+#include <fstream>
+
+#include "json_min.hpp"
+
+#include <algorithm>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace stn {
+namespace graphbind {
+
+namespace {
+
+using onnx::Model;
+using onnx::Node;
+using onnx::Tensor;
+
+enum Kind { EMBED, DWCONV, CONVK, LINEAR, LN, SCALE, OTHER };
+const char* kind_name(Kind k) {
+    static const char* n[] = {"embedding table (Gather)", "depthwise Conv", "k-tap Conv", "pointwise projection (Conv k=1 / MatMul / Gemm)",
+                              "LayerNormalization", "per-channel scale (Mul)", "unrecognised weighted operator"};
+    return n[k];
+}
+
+// one node that carries weights, in graph order
+struct Tok {
+    Kind kind = OTHER;
+    int node = -1;
+    std::string where;            // "node #i Op 'name'"
+    const Tensor* w = nullptr;    // weight / scale / table
+    const Tensor* b = nullptr;    // bias (LN: beta), may be absent
+    int out = 0, in = 0, k = 1, dil = 1;
+    bool transposed = false;      // LINEAR stored [in][out]
+    int heads = 0;                // head count of the first 4-D Reshape constant between this token and the next one
+};
+
+std::string dims_str(const Tensor* t) {
+    if (!t) return "(none)";
+    std::ostringstream o;
+    o << "[";
+    for (size_t i = 0; i < t->dims.size(); ++i) o << (i ? "," : "") << t->dims[i];
+    o << "]";
+    return o.str();
+}
+bool is_float(const Tensor* t) { return t && (t->data_type == onnx::FLOAT || t->data_type == onnx::FLOAT16 || t->data_type == onnx::BFLOAT16 || t->data_type == onnx::DOUBLE); }
+// dims with the 1s dropped
+std::vector<int64_t> squeezed(const Tensor* t) {
+    std::vector<int64_t> d;
+    for (int64_t v : t->dims) if (v != 1) d.push_back(v);
+    return d;
+}
+
+std::vector<Tok> weighted_nodes(const Model& m, const std::string& file) {
+    std::unordered_map<std::string, const Tensor*> init;
+    for (const Tensor& t : m.initializers) init[t.name] = &t;
+    auto get = [&](const Node& n, size_t i) -> const Tensor* {
+        if (i >= n.inputs.size()) return nullptr;
+        auto it = init.find(n.inputs[i]);
+        return it == init.end() ? nullptr : it->second;
+    };
+    std::vector<Tok> toks;
+    std::unordered_map<std::string, int> producer;  // value name -> index of the LINEAR token that produced it
+    for (size_t ni = 0; ni < m.nodes.size(); ++ni) {
+        const Node& n = m.nodes[ni];
+        Tok t;
+        t.node = (int)ni;
+        t.where = file + ": node #" + std::to_string(ni) + " " + n.op_type + " '" + n.name + "'";
+        bool emit = false;
+        if (n.op_type == "Gather") {
+            const Tensor* w = get(n, 0);
+            if (is_float(w) && w->dims.size() == 2) { t.kind = EMBED; t.w = w; t.out = (int)w->dims[0]; t.in = (int)w->dims[1]; emit = true; }
+        } else if (n.op_type == "Conv") {
+            const Tensor* w = get(n, 1);
+            if (!is_float(w) || w->dims.size() != 3) { t.kind = OTHER; t.w = w; emit = true; t.where += " (weight " + dims_str(w) + ": a 1-D convolution with a constant [Cout][Cin/group][k] weight is required)"; }
+            else {
+                const int64_t group = n.attr_i("group", 1), co = w->dims[0], cig = w->dims[1], k = w->dims[2];
+                t.w = w; t.b = get(n, 2); t.out = (int)co; t.k = (int)k; t.dil = (int)n.attr_i("dilations", 1);
+                if (group > 1) {
+                    if (group == co && cig == 1) { t.kind = DWCONV; t.in = (int)co; }
+                    else { t.kind = OTHER; t.where += " (group = " + std::to_string(group) + " with weight " + dims_str(w) + ": only depthwise grouping is part of the layout)"; }
+                } else if (k == 1) { t.kind = LINEAR; t.in = (int)cig; }
+                else { t.kind = CONVK; t.in = (int)cig; }
+                emit = true;
+            }
+        } else if (n.op_type == "MatMul") {
+            const Tensor *w1 = get(n, 1), *w0 = get(n, 0);
+            if (is_float(w1) && w1->dims.size() == 2) { t.kind = LINEAR; t.w = w1; t.in = (int)w1->dims[0]; t.out = (int)w1->dims[1]; t.transposed = true; emit = true; }
+            else if (is_float(w0) && w0->dims.size() == 2) { t.kind = LINEAR; t.w = w0; t.out = (int)w0->dims[0]; t.in = (int)w0->dims[1]; emit = true; }
+        } else if (n.op_type == "Gemm") {
+            const Tensor* w = get(n, 1);
+            if (is_float(w) && w->dims.size() == 2) {
+                const bool tb = n.attr_i("transB", 0) != 0;
+                t.kind = LINEAR; t.w = w; t.b = get(n, 2); t.transposed = !tb;
+                t.out = (int)(tb ? w->dims[0] : w->dims[1]); t.in = (int)(tb ? w->dims[1] : w->dims[0]);
+                emit = true;
+            }
+        } else if (n.op_type == "LayerNormalization") {
+            const Tensor* g = get(n, 1);
+            if (is_float(g)) { t.kind = LN; t.w = g; t.b = get(n, 2); t.out = t.in = (int)g->numel(); emit = true; }
+        } else if (n.op_type == "Add" || n.op_type == "Mul") {
+            const Tensor* c = is_float(get(n, 1)) ? get(n, 1) : (is_float(get(n, 0)) ? get(n, 0) : nullptr);
+            if (c && n.inputs.size() == 2) {
+                const std::string& other = n.inputs[get(n, 1) == c ? 0 : 1];
+                if (n.op_type == "Add") {  // MatMul + Add = projection with bias (a one-row projection has a one-element bias)
+                    auto p = producer.find(other);
+                    if (p != producer.end() && !toks[p->second].b && toks[p->second].out == (int)c->numel() && squeezed(c).size() <= 1) {
+                        toks[p->second].b = c;
+                        if (!n.outputs.empty()) producer[n.outputs[0]] = p->second;
+                        continue;
+                    }
+                }
+                if (c->numel() > 1) {  // scalars (attention scale, epsilons) are not weights
+                    if (squeezed(c).size() != 1) { t.kind = OTHER; t.w = c; emit = true; }
+                    else if (n.op_type == "Add") { t.kind = OTHER; t.w = c; emit = true; t.where += " (a constant vector added to something that is not a bias-free projection of that width)"; }
+                    else { t.kind = SCALE; t.w = c; t.out = t.in = (int)c->numel(); emit = true; }
+                }
+            }
+        } else if (n.op_type == "Reshape") {
+            const Tensor* s = get(n, 1);
+            if (s && s->data_type == onnx::INT64 && s->numel() == 4 && !toks.empty() && toks.back().heads == 0) {
+                const std::vector<float> v = onnx::to_float(*s);
+                if (v[2] > 0) toks.back().heads = (int)v[2];  // [batch, length, heads, head_dim]
+            }
+        } else {
+            for (size_t i = 0; i < n.inputs.size(); ++i) {
+                const Tensor* c = get(n, i);
+                if (is_float(c) && c->numel() > 1) { t.kind = OTHER; t.w = c; emit = true; break; }
+            }
+        }
+        if (!emit) continue;
+        if (t.kind == LINEAR && !n.outputs.empty()) producer[n.outputs[0]] = (int)toks.size();
+        toks.push_back(t);
+    }
+    return toks;
+}
+
+std::string arch_so_far(const stn_arch& a, const char* stage) {
+    std::ostringstream o;
+    const std::string s = stage;
+    if (s == "dp") o << "dp_dim=" << a.dp_dim << " dp_hidden=" << a.dp_hidden << " dp_kernel=" << a.dp_kernel << " dp_conv_blocks=" << a.dp_conv_blocks;
+    if (s == "te") o << "te_dim=" << a.te_dim << " te_hidden=" << a.te_hidden << " te_kernel=" << a.te_kernel << " te_conv_blocks=" << a.te_conv_blocks
+                     << " te_attn_blocks=" << a.te_attn_blocks << " te_ffn=" << a.te_ffn << " te_style_blocks=" << a.te_style_blocks;
+    if (s == "ve") o << "ve_dim=" << a.ve_dim << " ve_hidden=" << a.ve_hidden << " ve_kernel=" << a.ve_kernel << " ve_main_blocks=" << a.ve_main_blocks
+                     << " ve_dilated=" << a.ve_dilated << " ve_tail_blocks=" << a.ve_tail_blocks << " ve_time_dim=" << a.ve_time_dim;
+    if (s == "vo") o << "vo_dim=" << a.vo_dim << " vo_hidden=" << a.vo_hidden << " vo_kernel=" << a.vo_kernel << " vo_in_kernel=" << a.vo_in_kernel
+                     << " vo_blocks=" << a.vo_blocks;
+    return o.str();
+}
+
+// cursor over one graph's weighted nodes; every expect_* either binds canonical names or throws the diff
+struct Parser {
+    const std::vector<Tok>& t;
+    const std::string file;
+    const char* stage;
+    Result& r;
+    size_t i = 0;
+
+    const Tok* peek(size_t ahead = 0) const { return i + ahead < t.size() ? &t[i + ahead] : nullptr; }
+    bool next_is(Kind k, size_t ahead = 0) const { const Tok* p = peek(ahead); return p && p->kind == k; }
+
+    [[noreturn]] void fail(const std::string& canonical, const std::string& want) const {
+        std::ostringstream o;
+        o << file << ": the graph is not the embedding / ConvNeXt / attention layout this engine runs. At weighted node " << i << " of " << t.size()
+          << " the layout needs " << canonical << " = " << want << "; the graph has ";
+        if (const Tok* p = peek()) {
+            o << kind_name(p->kind) << " " << p->out << " <- " << p->in;
+            if (p->kind == DWCONV || p->kind == CONVK) o << ", k = " << p->k << ", dilation " << p->dil;
+            o << " (" << p->where << ", weight " << dims_str(p->w) << ")";
+        } else o << "no further weighted node";
+        o << ". Derived so far: " << arch_so_far(r.arch, stage);
+        throw std::runtime_error(o.str());
+    }
+    void bind(const std::string& name, const Tensor* ten, bool transpose, const Tok& tok) {
+        Bound b;
+        b.t = ten; b.transpose = transpose;
+        b.from = tok.where + (ten ? " initializer '" + ten->name + "' " + dims_str(ten) : " (no such input: zeros)");
+        r.tensors[name] = b;
+    }
+    static std::string shape(int out, int in) { return (out < 0 ? std::string("?") : std::to_string(out)) + " <- " + (in < 0 ? std::string("?") : std::to_string(in)); }
+
+    // out / in < 0: taken from the graph
+    const Tok& linear(const std::string& name, int out, int in) {
+        const Tok* p = peek();
+        if (!p || p->kind != LINEAR || (out >= 0 && p->out != out) || (in >= 0 && p->in != in)) fail(name, std::string(kind_name(LINEAR)) + " " + shape(out, in));
+        bind(name + ".w", p->w, p->transposed, *p);
+        bind(name + ".b", p->b, false, *p);
+        ++i;
+        return *p;
+    }
+    void ln(const std::string& name, int c) {
+        const Tok* p = peek();
+        if (!p || p->kind != LN || p->out != c) fail(name, std::string(kind_name(LN)) + " over " + std::to_string(c) + " channels");
+        bind(name + ".g", p->w, false, *p);
+        bind(name + ".b", p->b, false, *p);
+        ++i;
+    }
+    // ConvNeXt block: depthwise conv -> LayerNorm -> pw1 -> (GELU) -> pw2 -> layer scale.  c / hid / k < 0: set from the graph.
+    int convnext(const std::string& name, int& c, int& hid, int& k, int want_dil) {
+        const Tok* p = peek();
+        if (!p || p->kind != DWCONV || (c >= 0 && p->out != c) || (k >= 0 && p->k != k) || (want_dil > 0 && p->dil != want_dil))
+            fail(name + ".dw", std::string(kind_name(DWCONV)) + " over " + (c < 0 ? "?" : std::to_string(c)) + " channels, k = " + (k < 0 ? "?" : std::to_string(k)) +
+                                   (want_dil > 0 ? ", dilation " + std::to_string(want_dil) : std::string()));
+        c = p->out; k = p->k;
+        const int dil = p->dil;
+        bind(name + ".dw.w", p->w, false, *p);
+        bind(name + ".dw.b", p->b, false, *p);
+        ++i;
+        ln(name + ".ln", c);
+        hid = linear(name + ".pw1", hid, c).out;
+        linear(name + ".pw2", c, hid);
+        p = peek();
+        if (!p || p->kind != SCALE || p->out != c) fail(name + ".gamma", std::string(kind_name(SCALE)) + " over " + std::to_string(c) + " channels");
+        bind(name + ".gamma", p->w, false, *p);
+        ++i;
+        return dil;
+    }
+    // attention block: LayerNorm -> q, k, v projections -> (attention) -> output projection.  cctx < 0: from the graph.  Returns heads (0 = not in the graph).
+    int attn(const std::string& name, int c, int& cctx) {
+        ln(name + ".ln", c);
+        int heads = 0;
+        auto h = [&](const Tok& tk) { if (!heads) heads = tk.heads; };
+        h(linear(name + ".q", c, c));
+        const Tok& kk = linear(name + ".k", c, cctx);
+        cctx = kk.in;
+        h(kk);
+        h(linear(name + ".v", c, cctx));
+        linear(name + ".o", c, c);
+        return heads;
+    }
+    void done() {
+        if (i != t.size()) fail("(end of the graph)", "no further weighted node");
+    }
+};
+
+void set_heads(Result& r, int32_t& field, const char* fname, int found, int c) {
+    if (found > 0) {
+        if (c % found) throw std::runtime_error(std::string(fname) + " = " + std::to_string(found) + " (from a Reshape constant) does not divide the width " + std::to_string(c));
+        field = found;
+    } else r.notes += std::string(fname) + " is not readable from the graph (no [batch, length, heads, head_dim] Reshape constant inside the block): kept at " + std::to_string(field) + "; ";
+}
+void agree(const char* what, int from_graph, int from_json, const std::string& file) {
+    if (from_graph != from_json)
+        throw std::runtime_error(file + ": " + what + " = " + std::to_string(from_graph) + " by the graph's weight shapes, but tts.json says " + std::to_string(from_json));
+}
+
+}  // namespace
+
+Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Model& vem, const Model& vom) {
+    Result r;
+    r.arch = base;
+    stn_arch& a = r.arch;
+    auto S = [](const char* fmt, int i, int j = 0) { char b[64]; snprintf(b, sizeof b, fmt, i, j); return std::string(b); };
+    const int D = base.latent_dim * base.chunk_compress_factor;
+
+    {   // ---- duration predictor: embedding, ConvNeXt x n, style cross-attention, LayerNorm, two projections -------------------
+        const std::vector<Tok> toks = weighted_nodes(dpm, "duration_predictor.onnx");
+        Parser p{toks, "duration_predictor.onnx", "dp", r};
+        a.dp_conv_blocks = 0;
+        const Tok* e = p.peek();
+        if (!e || e->kind != EMBED) p.fail("dp.emb", std::string(kind_name(EMBED)) + " [vocab][dp_dim]");
+        a.vocab_size = e->out; a.dp_dim = e->in;
+        p.bind("dp.emb", e->w, false, *e);
+        ++p.i;
+        int c = a.dp_dim, hid = -1, k = -1;
+        while (p.next_is(DWCONV)) { p.convnext(S("dp.conv%d", a.dp_conv_blocks), c, hid, k, 1); ++a.dp_conv_blocks; a.dp_hidden = hid; a.dp_kernel = k; }
+        int cctx = -1;
+        set_heads(r, a.dp_heads, "dp_heads", p.attn("dp.st", c, cctx), c);
+        agree("d_style_dp (key projection of dp.st)", cctx, base.d_style_dp, p.file);
+        p.ln("dp.out_ln", c);
+        p.linear("dp.fc1", c, c);
+        p.linear("dp.fc2", 1, c);
+        p.done();
+    }
+    {   // ---- text encoder: embedding, ConvNeXt x n, {self-attention, FFN} x n, style cross-attention x n, LayerNorm, projection ---
+        const std::vector<Tok> toks = weighted_nodes(tem, "text_encoder.onnx");
+        Parser p{toks, "text_encoder.onnx", "te", r};
+        a.te_conv_blocks = a.te_attn_blocks = a.te_style_blocks = 0;
+        const Tok* e = p.peek();
+        if (!e || e->kind != EMBED) p.fail("te.emb", std::string(kind_name(EMBED)) + " [vocab][te_dim]");
+        if (e->out != a.vocab_size)
+            throw std::runtime_error("text_encoder.onnx: embedding table has " + std::to_string(e->out) + " rows, duration_predictor.onnx has " + std::to_string(a.vocab_size) + " (one unicode_indexer.json serves both)");
+        a.te_dim = e->in;
+        p.bind("te.emb", e->w, false, *e);
+        ++p.i;
+        int c = a.te_dim, hid = -1, k = -1, heads = 0;
+        while (p.next_is(DWCONV)) { p.convnext(S("te.conv%d", a.te_conv_blocks), c, hid, k, 1); ++a.te_conv_blocks; a.te_hidden = hid; a.te_kernel = k; }
+        // an attention block (LN q k v o) followed by LN + two projections is a self-attention block with its FFN; without them it
+        // is a style cross-attention block; LN + ONE projection ends the graph
+        int ffn = -1;
+        while (p.next_is(LN) && p.next_is(LINEAR, 1) && p.next_is(LINEAR, 2)) {
+            const bool has_ffn = p.next_is(LN, 5) && p.next_is(LINEAR, 6) && p.next_is(LINEAR, 7) && !p.next_is(LINEAR, 8);
+            if (has_ffn) {
+                if (a.te_style_blocks) p.fail("te.st" + std::to_string(a.te_style_blocks), "a style cross-attention block (self-attention blocks come first)");
+                const std::string n = S("te.sa%d", a.te_attn_blocks);
+                int cctx = c;
+                const int h = p.attn(n, c, cctx);
+                if (!heads) heads = h;
+                p.ln(n + ".ffn_ln", c);
+                ffn = p.linear(n + ".ffn1", ffn, c).out;
+                p.linear(n + ".ffn2", c, ffn);
+                a.te_ffn = ffn;
+                ++a.te_attn_blocks;
+            } else {
+                int cctx = base.d_style_ttl;
+                const int h = p.attn(S("te.st%d", a.te_style_blocks), c, cctx);
+                if (!heads) heads = h;
+                ++a.te_style_blocks;
+            }
+        }
+        set_heads(r, a.te_heads, "te_heads", heads, c);
+        p.ln("te.out_ln", c);
+        const int odim = p.linear("te.proj", -1, c).out;
+        agree("te_out_dim (rows of te.proj)", odim, base.te_out_dim, p.file);
+        p.done();
+    }
+    {   // ---- vector estimator ---------------------------------------------------------------------------------------------
+        const std::vector<Tok> toks = weighted_nodes(vem, "vector_estimator.onnx");
+        Parser p{toks, "vector_estimator.onnx", "ve", r};
+        a.ve_main_blocks = a.ve_tail_blocks = 0;
+        const Tok& in = p.linear("ve.in", -1, -1);
+        a.ve_dim = in.out;
+        agree("latent_dim * chunk_compress_factor (columns of ve.in)", in.in, D, p.file);
+        int c = a.ve_dim;
+        a.ve_time_dim = p.linear("ve.t1", c, -1).in;
+        p.linear("ve.t2", c, c);
+        int hid = -1, k = -1, heads = 0, dilated = -1;
+        a.ve_dilated = 0;
+        auto cn = [&](const std::string& name, int dil) { p.convnext(name, c, hid, k, dil); a.ve_hidden = hid; a.ve_kernel = k; };
+        // Only a main block's time projection is a projection followed directly by a depthwise conv with nothing but ConvNeXt
+        // blocks before it: while one lies ahead, the ConvNeXt run in front of it is a main block's dilated run (dilation 2^j);
+        // the last run, followed by LayerNorm, is the tail.
+        auto main_block_ahead = [&]() {
+            for (size_t j = 0; p.peek(j + 1); ++j) {
+                const Tok* t0 = p.peek(j);
+                if (t0->kind == LINEAR && p.peek(j + 1)->kind == DWCONV && t0->out == c && t0->in == c) return true;
+                if (t0->kind == LN && j > 0 && p.peek(j - 1)->kind != DWCONV) return false;  // an attention / output LayerNorm: past the run
+            }
+            return false;
+        };
+        while (p.next_is(DWCONV) || (p.next_is(LINEAR) && p.next_is(DWCONV, 1))) {  // (a main block without dilated blocks opens with its time projection)
+            if (!main_block_ahead()) {
+                while (p.next_is(DWCONV)) { cn(S("ve.tail%d", a.ve_tail_blocks), 1); ++a.ve_tail_blocks; }
+                break;
+            }
+            const int b = a.ve_main_blocks;
+            int j = 0;
+            while (dilated < 0 ? p.next_is(DWCONV) : j < dilated) { cn(S("ve.m%d.dil%d", b, j), 1 << j); ++j; }
+            if (dilated < 0) { dilated = j; a.ve_dilated = j; }
+            p.linear(S("ve.m%d.time", b), c, c);
+            cn(S("ve.m%d.cn_a", b), 1);
+            int cctx = base.te_out_dim;
+            int h = p.attn(S("ve.m%d.text", b), c, cctx);
+            if (!heads) heads = h;
+            cn(S("ve.m%d.cn_b", b), 1);
+            cctx = base.d_style_ttl;
+            h = p.attn(S("ve.m%d.style", b), c, cctx);
+            if (!heads) heads = h;
+            ++a.ve_main_blocks;
+        }
+        set_heads(r, a.ve_heads, "ve_heads", heads, c);
+        p.ln("ve.out_ln", c);
+        p.linear("ve.out", D, c);
+        p.done();
+    }
+    {   // ---- vocoder: k-tap input conv, ConvNeXt x n (per-block dilation), LayerNorm, head --------------------------------------
+        const std::vector<Tok> toks = weighted_nodes(vom, "vocoder.onnx");
+        Parser p{toks, "vocoder.onnx", "vo", r};
+        a.vo_blocks = 0;
+        const Tok* e = p.peek();
+        if (!e || (e->kind != CONVK && e->kind != LINEAR) || e->in != base.latent_dim)
+            p.fail("vo.in", std::string(kind_name(CONVK)) + " vo_dim <- " + std::to_string(base.latent_dim) + " (latent_dim of tts.json)");
+        a.vo_dim = e->out; a.vo_in_kernel = e->k;
+        p.bind("vo.in.w", e->w, false, *e);
+        p.bind("vo.in.b", e->b, false, *e);
+        if (e->kind == LINEAR && e->transposed) p.fail("vo.in", "a Conv (a MatMul cannot be the k-tap input convolution)");
+        ++p.i;
+        int c = a.vo_dim, hid = -1, k = -1;
+        while (p.next_is(DWCONV)) {
+            if (a.vo_blocks >= STN_MAX_VO_BLOCKS) p.fail("vo.blk" + std::to_string(a.vo_blocks), "at most " + std::to_string(STN_MAX_VO_BLOCKS) + " vocoder blocks (STN_MAX_VO_BLOCKS)");
+            a.vo_dilations[a.vo_blocks] = p.convnext(S("vo.blk%d", a.vo_blocks), c, hid, k, 0);
+            ++a.vo_blocks;
+            a.vo_hidden = hid; a.vo_kernel = k;
+        }
+        p.ln("vo.out_ln", c);
+        const int chunk = p.linear("vo.head", -1, c).out;
+        agree("base_chunk_size (rows of vo.head)", chunk, base.base_chunk_size, p.file);
+        p.done();
+    }
+    return r;
+}
+
+stn_arch arch_from_config(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("Failed to open " + path);
+    const std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    using json::Value;
+    const Value cfg = json::parse(text);
+    stn_arch a;
+    stn_arch_default(&a);
+    a.sample_rate = cfg.at("ae").at("sample_rate").as_int();
+    a.base_chunk_size = cfg.at("ae").at("base_chunk_size").as_int();
+    a.chunk_compress_factor = cfg.at("ttl").at("chunk_compress_factor").as_int();
+    a.latent_dim = cfg.at("ttl").at("latent_dim").as_int();
+    auto opt = [](const Value& v, std::initializer_list<const char*> keys, int32_t& dst) {
+        const Value* cur = &v;
+        for (const char* k : keys) { if (!cur->is_object() || !cur->has(k)) return; cur = &cur->at(k); }
+        if (cur->type == Value::Number) dst = (int32_t)cur->num;
+    };
+    opt(cfg, {"ttl", "style_encoder", "style_token_layer", "n_style"}, a.n_style_ttl);
+    opt(cfg, {"ttl", "style_encoder", "style_token_layer", "style_value_dim"}, a.d_style_ttl);
+    opt(cfg, {"ttl", "text_encoder", "proj_out", "odim"}, a.te_out_dim);
+    opt(cfg, {"dp", "style_encoder", "style_token_layer", "n_style"}, a.n_style_dp);
+    opt(cfg, {"dp", "style_encoder", "style_token_layer", "style_value_dim"}, a.d_style_dp);
+    return a;
+}
+
+void check_all_io_names(const Model& dp, const Model& te, const Model& ve, const Model& vo) {
+    // the names every host feeds and fetches (/root/reference/cpp/helper.cpp:512-513, 545-546, 620-623, 663-664)
+    check_io_names(dp, "duration_predictor.onnx", {"text_ids", "style_dp", "text_mask"}, {"duration"});
+    check_io_names(te, "text_encoder.onnx", {"text_ids", "style_ttl", "text_mask"}, {"text_emb"});
+    check_io_names(ve, "vector_estimator.onnx", {"noisy_latent", "text_emb", "style_ttl", "text_mask", "latent_mask", "total_step", "current_step"},
+                   {"denoised_latent"});
+    check_io_names(vo, "vocoder.onnx", {"latent"}, {"wav_tts"});
+}
+
+std::string bind_dir_json(const std::string& dir) {
+    const stn_arch base = arch_from_config(dir + "/tts.json");
+    const Model dp = onnx::parse_file(dir + "/duration_predictor.onnx"), te = onnx::parse_file(dir + "/text_encoder.onnx"),
+                ve = onnx::parse_file(dir + "/vector_estimator.onnx"), vo = onnx::parse_file(dir + "/vocoder.onnx");
+    check_all_io_names(dp, te, ve, vo);
+    const Result r = bind(base, dp, te, ve, vo);
+    auto esc = [](const std::string& s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o.push_back('\\'); o.push_back(c); } return o; };
+    std::ostringstream o;
+    const stn_arch& a = r.arch;
+    o << "{\"arch\":{";
+#define F(x) "\"" #x "\":" << a.x
+    o << F(sample_rate) << "," << F(base_chunk_size) << "," << F(chunk_compress_factor) << "," << F(latent_dim) << "," << F(vocab_size) << ","
+      << F(n_style_ttl) << "," << F(d_style_ttl) << "," << F(n_style_dp) << "," << F(d_style_dp) << ","
+      << F(te_dim) << "," << F(te_hidden) << "," << F(te_kernel) << "," << F(te_conv_blocks) << "," << F(te_attn_blocks) << "," << F(te_heads) << ","
+      << F(te_ffn) << "," << F(te_style_blocks) << "," << F(te_out_dim) << ","
+      << F(dp_dim) << "," << F(dp_hidden) << "," << F(dp_kernel) << "," << F(dp_conv_blocks) << "," << F(dp_heads) << ","
+      << F(ve_dim) << "," << F(ve_hidden) << "," << F(ve_kernel) << "," << F(ve_main_blocks) << "," << F(ve_dilated) << "," << F(ve_tail_blocks) << ","
+      << F(ve_heads) << "," << F(ve_time_dim) << ","
+      << F(vo_dim) << "," << F(vo_hidden) << "," << F(vo_kernel) << "," << F(vo_blocks) << "," << F(vo_in_kernel) << ",\"vo_dilations\":[";
+#undef F
+    for (int i = 0; i < a.vo_blocks; ++i) o << (i ? "," : "") << a.vo_dilations[i];
+    o << "]},\"tensors\":{";
+    bool first = true;
+    for (const auto& kv : r.tensors) {
+        o << (first ? "" : ",") << "\"" << kv.first << "\":{\"from\":\"" << esc(kv.second.from) << "\",\"transpose\":" << (kv.second.transpose ? "true" : "false")
+          << ",\"zeros\":" << (kv.second.t ? "false" : "true") << "}";
+        first = false;
+    }
+    o << "},\"notes\":\"" << esc(r.notes) << "\"}";
+    return o.str();
+}
+
+void check_io_names(const Model& m, const std::string& file, const std::vector<std::string>& inputs, const std::vector<std::string>& outputs) {
+    // older exporters list the initializers among the graph inputs as well
+    std::vector<std::string> in;
+    for (const std::string& n : m.inputs) if (!m.find(n)) in.push_back(n);
+    auto join = [](const std::vector<std::string>& v) { std::string s; for (auto& x : v) s += (s.empty() ? "" : ", ") + x; return "{" + s + "}"; };
+    auto same_set = [](std::vector<std::string> x, std::vector<std::string> y) { std::sort(x.begin(), x.end()); std::sort(y.begin(), y.end()); return x == y; };
+    if (!same_set(in, inputs)) throw std::runtime_error(file + ": graph inputs are " + join(in) + ", the host feeds " + join(inputs));
+    if (!same_set(m.outputs, outputs)) throw std::runtime_error(file + ": graph outputs are " + join(m.outputs) + ", the host fetches " + join(outputs));
+}
+
+std::vector<float> fetch(const Bound& b, const std::string& canonical, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    if (!b.t) return std::vector<float>(n, 0.f);
+    std::vector<float> v = onnx::to_float(*b.t);
+    if (v.size() != n)
+        throw std::runtime_error(canonical + ": " + b.from + " has " + std::to_string(v.size()) + " elements, descriptor wants " + std::to_string(rows) + "x" + std::to_string(cols));
+    if (b.transpose) {
+        std::vector<float> w(n);
+        for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) w[(size_t)r * cols + c] = v[(size_t)c * rows + r];
+        v.swap(w);
+    }
+    return v;
+}
+
+}  // namespace graphbind
+}  // namespace stn

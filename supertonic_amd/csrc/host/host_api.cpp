@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../../include/stn.h"
+#include "graph_bind.hpp"
 #include "onnx_reader.hpp"
 #include "text_frontend.hpp"
 #include "tts_host.hpp"
@@ -95,6 +96,14 @@ int64_t stn_onnx_summary(const char* path, char* out, size_t cap) {
     const int64_t rc = guarded([&]() -> int64_t {
         if (!path) throw std::runtime_error("null argument");
         return emit(stn::onnx::summary_json(stn::onnx::parse_file(path)), out, cap);
+    });
+    return rc < 0 ? STN_ERR_IO : rc;
+}
+
+int64_t stn_bind_graphs(const char* onnx_dir, char* out, size_t cap) {
+    const int64_t rc = guarded([&]() -> int64_t {
+        if (!onnx_dir) throw std::runtime_error("null argument");
+        return emit(stn::graphbind::bind_dir_json(onnx_dir), out, cap);
     });
     return rc < 0 ? STN_ERR_IO : rc;
 }

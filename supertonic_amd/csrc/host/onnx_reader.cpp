@@ -75,8 +75,28 @@ Tensor parse_tensor(Reader r) {
     }
     return t;
 }
-Node parse_node(Reader r) {
+// AttributeProto{name = 1, i = 3, t = 5, ints = 8}: integers into n.ints, a tensor (Constant's "value") into *tensor_out
+void parse_attribute(Reader r, Node& n, std::vector<Tensor>* tensor_out) {
+    std::string name;
+    std::vector<int64_t> vals;
+    bool have = false;
+    Tensor t;
+    bool have_t = false;
+    while (!r.done()) {
+        const uint64_t key = r.varint();
+        const int field = (int)(key >> 3), wire = (int)(key & 7);
+        if (field == 1 && wire == 2) name = r.str();
+        else if (field == 3 && wire == 0) { vals.push_back((int64_t)r.varint()); have = true; }
+        else if (field == 8) { repeated_scalar(r, wire, vals, [](Reader& s) { return (int64_t)s.varint(); }, 0); have = true; }
+        else if (field == 5 && wire == 2) { t = parse_tensor(r.sub()); have_t = true; }
+        else r.skip(wire);
+    }
+    if (have) n.ints[name] = std::move(vals);
+    if (have_t && tensor_out && name == "value") tensor_out->push_back(std::move(t));
+}
+Node parse_node(Reader r, std::vector<Tensor>* constants) {
     Node n;
+    std::vector<Tensor> vals;
     while (!r.done()) {
         const uint64_t key = r.varint();
         const int field = (int)(key >> 3), wire = (int)(key & 7);
@@ -85,8 +105,13 @@ Node parse_node(Reader r) {
             case 2: n.outputs.push_back(r.str()); break;
             case 3: n.name = r.str(); break;
             case 4: n.op_type = r.str(); break;
+            case 5: if (wire == 2) parse_attribute(r.sub(), n, &vals); else r.skip(wire); break;
             default: r.skip(wire);
         }
+    }
+    if (n.op_type == "Constant" && !vals.empty() && !n.outputs.empty() && constants) {
+        vals[0].name = n.outputs[0];
+        constants->push_back(std::move(vals[0]));
     }
     return n;
 }
@@ -105,7 +130,7 @@ void parse_graph(Reader r, Model& m) {
         const int field = (int)(key >> 3), wire = (int)(key & 7);
         if (wire != 2) { r.skip(wire); continue; }
         switch (field) {
-            case 1: m.nodes.push_back(parse_node(r.sub())); break;
+            case 1: m.nodes.push_back(parse_node(r.sub(), &m.initializers)); break;
             case 5: m.initializers.push_back(parse_tensor(r.sub())); break;
             case 11: m.inputs.push_back(parse_value_info_name(r.sub())); break;
             case 12: m.outputs.push_back(parse_value_info_name(r.sub())); break;

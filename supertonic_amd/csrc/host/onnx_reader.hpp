@@ -1,9 +1,11 @@
 // onnx_reader.hpp — minimal reader for the parts of an ONNX ModelProto the engine needs: graph initializers (weights),
-// node op types (for a sanity dump) and graph input/output names.  Hand-written protobuf wire parsing; neither `onnx` nor
+// nodes (op type, edges, integer attributes; the tensor of a Constant node joins the initializers under the node's output name) and
+// graph input/output names.  Hand-written protobuf wire parsing; neither `onnx` nor
 // `protobuf` C++ exist in this image.  Replaces what `Ort::Session(env, path, opts)` does with the file at model-load time
 // (/root/reference/cpp/helper.cpp:776-795).
 #pragma once
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -25,7 +27,13 @@ struct Tensor {
     bool external = false;            // data_location == EXTERNAL: not supported
     int64_t numel() const;
 };
-struct Node { std::string op_type, name; std::vector<std::string> inputs, outputs; };
+struct Node {
+    std::string op_type, name;
+    std::vector<std::string> inputs, outputs;
+    std::map<std::string, std::vector<int64_t>> ints;  // INT and INTS attributes (group, dilations, kernel_shape, transB, axis ...)
+    const std::vector<int64_t>* attr(const std::string& k) const { auto it = ints.find(k); return it == ints.end() ? nullptr : &it->second; }
+    int64_t attr_i(const std::string& k, int64_t dflt) const { auto* v = attr(k); return v && !v->empty() ? (*v)[0] : dflt; }
+};
 
 struct Model {
     int64_t ir_version = 0;

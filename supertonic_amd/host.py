@@ -27,6 +27,8 @@ def _lib():
         L.stn_sanitize_filename.argtypes = [c, ctypes.c_int, ctypes.c_void_p, sz]
         L.stn_onnx_summary.restype = i64
         L.stn_onnx_summary.argtypes = [c, ctypes.c_void_p, sz]
+        L.stn_bind_graphs.restype = i64
+        L.stn_bind_graphs.argtypes = [c, ctypes.c_void_p, sz]
         L.stn_wav_encode.restype = i64
         L.stn_wav_encode.argtypes = [ctypes.c_void_p, sz, ctypes.c_int, ctypes.c_void_p, sz]
         L.stn_write_wav.argtypes = [c, ctypes.c_void_p, sz, ctypes.c_int]
@@ -130,6 +132,19 @@ def onnx_summary(path: str) -> dict:
         raise OSError(L.stn_host_last_error().decode())
     buf = ctypes.create_string_buffer(n + 1)
     L.stn_onnx_summary(path.encode(), buf, n + 1)
+    return json.loads(buf.value.decode())
+
+
+def bind_graphs(onnx_dir: str) -> dict:
+    """The manifest-less binding of an asset directory (descriptor from the graphs' weight shapes, canonical tensor -> initializer),
+    computed on the host only; raises OSError with the loader's diff when the graphs are not the engine's layout."""
+    import json
+    L = _lib()
+    n = L.stn_bind_graphs(onnx_dir.encode(), None, 0)
+    if n < 0:
+        raise OSError(L.stn_host_last_error().decode())
+    buf = ctypes.create_string_buffer(n + 1)
+    L.stn_bind_graphs(onnx_dir.encode(), buf, n + 1)
     return json.loads(buf.value.decode())
 
 

@@ -1,7 +1,8 @@
 """Hand-encoded ONNX ModelProto files for the loader tests (neither `onnx` nor ONNX Runtime exist offline).
 Only the protobuf wire format is used: ModelProto{ir_version=1, producer_name=2, graph=7},
 GraphProto{node=1, name=2, initializer=5, input=11, output=12}, TensorProto{dims=1, data_type=2, float_data=4,
-int64_data=7, name=8, raw_data=9}, NodeProto{input=1, output=2, name=3, op_type=4}."""
+int64_data=7, name=8, raw_data=9}, NodeProto{input=1, output=2, name=3, op_type=4, attribute=5},
+AttributeProto{name=1, i=3, t=5, ints=8, type=20}."""
 import struct
 
 import numpy as np
@@ -48,9 +49,26 @@ def tensor(name, arr, style="raw"):
     return body
 
 
-def node(op_type, inputs, outputs, name=""):
+def attr_int(name, v):
+    return _ld(1, name.encode()) + _key(3, 0) + _varint(int(v)) + _key(20, 0) + _varint(2)  # type INT
+
+
+def attr_ints(name, vs, packed=True):
+    body = _ld(1, name.encode())
+    if packed:
+        body += _ld(8, b"".join(_varint(int(v)) for v in vs))
+    else:
+        body += b"".join(_key(8, 0) + _varint(int(v)) for v in vs)
+    return body + _key(20, 0) + _varint(7)  # type INTS
+
+
+def attr_tensor(name, tensor_body):
+    return _ld(1, name.encode()) + _ld(5, tensor_body) + _key(20, 0) + _varint(4)  # type TENSOR
+
+
+def node(op_type, inputs, outputs, name="", attrs=()):
     body = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
-    return body + _ld(3, name.encode()) + _ld(4, op_type.encode())
+    return body + _ld(3, name.encode()) + _ld(4, op_type.encode()) + b"".join(_ld(5, a) for a in attrs)
 
 
 def value_info(name):

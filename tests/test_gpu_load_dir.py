@@ -12,6 +12,7 @@ from supertonic_amd import binding, host
 from supertonic_amd.arch import tiny_arch
 from gpu_util import make_inputs
 import onnx_writer as ow
+from onnx_graphs import build_graph_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -101,7 +102,8 @@ def test_load_dir_error_paths(tmp_path):
         eng.load_dir(str(tmp_path))  # empty directory: like cpp/helper.cpp:805
     man = build_asset_dir(tmp_path, a, ref, eng)
     (tmp_path / "stn_weight_map.json").rename(tmp_path / "m.json")
-    with pytest.raises(binding.StnError, match="no weight manifest.*initializers"):
+    # without the manifest the loader reads the nodes, and these files hold initializers but no layers
+    with pytest.raises(binding.StnError, match=r"duration_predictor\.onnx: the graph is not the embedding / ConvNeXt / attention layout.*dp\.emb"):
         eng.load_dir(str(tmp_path))
     broken = dict(man)
     broken["tensors"] = dict(man["tensors"])
@@ -112,4 +114,64 @@ def test_load_dir_error_paths(tmp_path):
     broken["tensors"]["vo.head.w"] = {"file": "vocoder.onnx", "name": "/model/vo/head/b"}
     (tmp_path / "stn_weight_map.json").write_text(json.dumps(broken))
     with pytest.raises(binding.StnError, match="elements, descriptor wants"):
+        eng.load_dir(str(tmp_path))
+
+
+def _same_as_synthetic(a, seed, eng, dtype="f32"):
+    synth = binding.Engine(0, dtype)
+    synth.load_synthetic(a, seed)
+    assert eng.param_count == synth.param_count
+    ids, mask, sttl, sdp = make_inputs(a, 2, 12, [12, 7], seed=2)
+    durs = np.array([0.3, 0.12], np.float32)
+    w0, d0 = synth.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=9)
+    w1, d1 = eng.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=9)
+    assert np.array_equal(w0, w1) and np.array_equal(d0, d1)
+    assert np.array_equal(synth.duration(ids, sdp, mask), eng.duration(ids, sdp, mask))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_load_dir_without_a_manifest_binds_the_graph_nodes(tmp_path, dtype):
+    """Real node graphs, exporter-style initializer names, no stn_weight_map.json: the descriptor and the tensor binding come
+    out of the nodes (host/graph_bind.cpp) and the loaded engine equals the one with the same weights generated in place."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    build_graph_dir(tmp_path, a, ref.tensor)
+    eng = binding.Engine(0, dtype)
+    eng.load_dir(str(tmp_path))
+    got = eng.arch
+    for f in ("ve_dim", "ve_hidden", "ve_main_blocks", "ve_dilated", "ve_tail_blocks", "ve_heads", "te_attn_blocks", "te_style_blocks", "te_heads",
+              "dp_conv_blocks", "dp_heads", "vo_blocks", "vo_kernel", "vo_in_kernel", "vocab_size", "te_ffn"):
+        assert getattr(got, f) == getattr(a, f), f
+    assert list(got.vo_dilations)[:a.vo_blocks] == list(a.vo_dilations)[:a.vo_blocks]
+    _same_as_synthetic(a, 7, eng, dtype)
+
+
+def test_load_dir_without_a_manifest_other_depths_and_widths(tmp_path):
+    a = tiny_arch()
+    a.vo_blocks, a.ve_main_blocks, a.ve_dilated, a.ve_tail_blocks, a.te_attn_blocks, a.te_style_blocks = 2, 1, 3, 2, 1, 2
+    a.vo_dim, a.vo_hidden, a.dp_conv_blocks, a.vo_kernel = 48, 96, 1, 5
+    a.vo_dilations[0], a.vo_dilations[1] = 1, 3
+    ref = RefModel(a, 11)
+    build_graph_dir(tmp_path, a, ref.tensor)
+    eng = binding.Engine(0, "f32")
+    eng.load_dir(str(tmp_path))
+    assert (eng.arch.vo_blocks, eng.arch.vo_dim, eng.arch.ve_dilated, eng.arch.te_style_blocks) == (2, 48, 3, 2)
+    _same_as_synthetic(a, 11, eng)
+
+
+def test_load_dir_without_a_manifest_reports_the_mismatch(tmp_path):
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    eng = binding.Engine(0, "f32")
+    build_graph_dir(tmp_path, a, ref.tensor, breaks={"vo.blk1": "width"})
+    with pytest.raises(binding.StnError, match=r"vocoder\.onnx.*vo\.blk1\.dw = depthwise Conv over 64 channels.*depthwise Conv 72 <- 72.*\[72,1,7\]"):
+        eng.load_dir(str(tmp_path))
+    build_graph_dir(tmp_path, a, ref.tensor, breaks={"ve.m0.dil1": "no_gamma"})
+    with pytest.raises(binding.StnError, match=r"vector_estimator\.onnx.*ve\.m0\.dil1\.gamma"):
+        eng.load_dir(str(tmp_path))
+    # a depth the engine cannot run is an error code from the descriptor check, with the field's name
+    b = tiny_arch()
+    b.ve_dim, b.ve_heads = 100, 2  # head dim 50: not a multiple of 8
+    build_graph_dir(tmp_path, b, RefModel(b, 7).tensor)
+    with pytest.raises(binding.StnError, match=r"ve_dim = 100|ve_heads = 2"):
         eng.load_dir(str(tmp_path))
