@@ -1,9 +1,12 @@
 """Stage-level and end-to-end parity on a real MI355X, through the C ABI, against the CPU oracle
 (oracle/stn_ref.c) on identical synthetic weights, identical inputs and injected noise.
 
-Stated tolerances (max |diff| and rms diff, both relative to the rms of the oracle output):
+Tolerances (max |diff| and rms diff, both relative to the rms of the oracle output): every case is held to <= 2x the error
+measured for it on an MI355X (tests/golden/parity_bounds.json, recorded by tools/parity_record.py into profiles/parity_r02.json),
+and never looser than the mode's ceiling in gpu_util.CEILING:
   fp32 engine : per stage max <= 2e-4 ; end-to-end waveform max <= 2e-3 (5 Euler steps + vocoder compound)
-  bf16 engine : per stage rms <= 2e-2, max <= 1e-1 ; end-to-end rms <= 5e-2
+  bf16 engine : per stage rms <= 2e-2, max <= 1e-1 ; end-to-end rms <= 5e-2, max <= 3e-1
+  f16  engine : 8x tighter than bf16
 (bf16 = bf16 GEMM operands and inter-kernel activations, fp32 accumulate, fp32 residual stream.)"""
 import numpy as np
 import pytest
@@ -12,15 +15,9 @@ from oracle import host_ref
 from oracle.neural_ref import RefModel, randn
 from supertonic_amd import binding
 from supertonic_amd.arch import default_arch, tiny_arch
-from gpu_util import make_inputs, rel_err
+from gpu_util import CEILING, make_inputs, parity_check, rel_err
 
 pytestmark = pytest.mark.gpu
-
-TOL = {"f32": dict(stage_max=2e-4, stage_rms=5e-5, e2e_max=2e-3, e2e_rms=5e-4),
-       "bf16": dict(stage_max=1e-1, stage_rms=2e-2, e2e_max=3e-1, e2e_rms=5e-2),
-       # IEEE half (STN_DTYPE_F16): 3 more mantissa bits than bf16 -> 8x tighter bounds
-       "f16": dict(stage_max=1.5e-2, stage_rms=3e-3, e2e_max=4e-2, e2e_rms=8e-3)}
-
 
 @pytest.fixture(scope="module")
 def ref_tiny():
@@ -35,12 +32,6 @@ def eng_tiny(request):
     return e
 
 
-def check(got, ref, tol_max, tol_rms, what):
-    mx, rms = rel_err(got, ref)
-    assert np.all(np.isfinite(got)), what
-    assert mx <= tol_max and rms <= tol_rms, f"{what}: max {mx:.3e} (tol {tol_max}) rms {rms:.3e} (tol {tol_rms})"
-
-
 def test_param_count_matches_oracle(eng_tiny, ref_tiny):
     assert eng_tiny.param_count == ref_tiny.param_count
 
@@ -48,16 +39,14 @@ def test_param_count_matches_oracle(eng_tiny, ref_tiny):
 def test_duration(eng_tiny, ref_tiny):
     a = tiny_arch()
     ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5])
-    t = TOL[eng_tiny.mode]
-    check(eng_tiny.duration(ids, sdp, mask), ref_tiny.duration(ids, sdp, mask), t["stage_max"], t["stage_rms"], "duration")
+    parity_check("tiny.duration", eng_tiny.mode, eng_tiny.duration(ids, sdp, mask), ref_tiny.duration(ids, sdp, mask))
 
 
 def test_text_enc(eng_tiny, ref_tiny):
     a = tiny_arch()
     ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5])
     got, ref = eng_tiny.text_enc(ids, sttl, mask), ref_tiny.text_enc(ids, sttl, mask)
-    t = TOL[eng_tiny.mode]
-    check(got, ref, t["stage_max"], t["stage_rms"], "text_emb")
+    parity_check("tiny.text_emb", eng_tiny.mode, got, ref)
     assert np.all(got[1, :, 9:] == 0) and np.all(got[2, :, 5:] == 0)  # padded tokens are exactly zero
 
 
@@ -71,16 +60,14 @@ def test_vector_est(eng_tiny, ref_tiny):
     ts, cs = np.full(3, 4, np.float32), np.array([0, 1, 3], np.float32)
     got = eng_tiny.vector_est(x, emb, sttl, mask, lmask, ts, cs)
     ref = ref_tiny.vector_est(x, emb, sttl, mask, lmask, ts, cs)
-    t = TOL[eng_tiny.mode]
-    check(got, ref, t["stage_max"], t["stage_rms"], "denoised_latent")
+    parity_check("tiny.denoised_latent", eng_tiny.mode, got, ref)
     assert np.all(got[1, :, 5:] == 0) and np.all(got[2, :, 2:] == 0)
 
 
 def test_vocoder(eng_tiny, ref_tiny):
     a = tiny_arch()
     lat = randn(11, 2, a.latent_channels, 7)
-    t = TOL[eng_tiny.mode]
-    check(eng_tiny.vocoder(lat), ref_tiny.vocoder(lat), t["stage_max"], t["stage_rms"], "wav")
+    parity_check("tiny.vocoder_wav", eng_tiny.mode, eng_tiny.vocoder(lat), ref_tiny.vocoder(lat))
 
 
 def test_synthesize_end_to_end_injected_noise(eng_tiny, ref_tiny):
@@ -98,8 +85,7 @@ def test_synthesize_end_to_end_injected_noise(eng_tiny, ref_tiny):
     wav, dur = eng_tiny.synthesize(ids, mask, sttl, sdp, 3, 1.05, noise=noise["x"], duration_override=durs)
     assert wav.shape == ref_wav.shape
     np.testing.assert_allclose(dur, ref_dur, rtol=1e-6)
-    t = TOL[eng_tiny.mode]
-    check(wav, ref_wav, t["e2e_max"], t["e2e_rms"], "e2e wav")
+    parity_check("tiny.e2e_wav", eng_tiny.mode, wav, ref_wav, "e2e")
 
 
 def test_synthesize_predicted_durations_and_device_noise(eng_tiny, ref_tiny):
@@ -108,12 +94,10 @@ def test_synthesize_predicted_durations_and_device_noise(eng_tiny, ref_tiny):
     ids, mask, sttl, sdp = make_inputs(a, 2, 12, [12, 8], seed=9)
     wav, dur = eng_tiny.synthesize(ids, mask, sttl, sdp, 2, 1.0, noise_seed=42)
     ref_wav, ref_dur = ref_tiny.synthesize(ids, mask, sttl, sdp, 2, 1.0, lambda B, D, L: randn(42, B, D, L))
-    t = TOL[eng_tiny.mode]
-    np.testing.assert_allclose(dur, ref_dur, rtol=max(t["stage_max"], 1e-5))
-    if wav.shape == ref_wav.shape:  # bf16 durations may land on the other side of a frame boundary
-        check(wav, ref_wav, t["e2e_max"], t["e2e_rms"], "e2e wav (device noise)")
-    else:
-        assert eng_tiny.mode in ("bf16", "f16")
+    # the duration predictor runs in fp32 in every mode: the same lengths, hence the same shapes, in all three
+    np.testing.assert_allclose(dur, ref_dur, rtol=1e-5)
+    assert wav.shape == ref_wav.shape
+    parity_check("tiny.e2e_wav_device_noise", eng_tiny.mode, wav, ref_wav, "e2e")
 
 
 def test_sharding_invariance(eng_tiny):
@@ -163,5 +147,4 @@ def test_full_model_single_utterance(mode):
     ref_wav, ref_dur = ref.synthesize(ids, mask, sttl, sdp, 5, 1.05, nf, duration_override=durs)
     wav, dur = eng.synthesize(ids, mask, sttl, sdp, 5, 1.05, noise=nz["x"], duration_override=durs)
     assert wav.shape == (1, 49 * 3072)
-    t = TOL[mode]
-    check(wav, ref_wav, t["e2e_max"], t["e2e_rms"], "C1 wav")
+    parity_check("c1.full_single_utterance_wav", mode, wav, ref_wav, "e2e")
