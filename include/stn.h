@@ -119,13 +119,9 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * latent frames each utterance owns (sum of lengths rows), 0 = padded [b*L + t] rows with the padding masked to zero after
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
-/* Cross-attention blocks of the vector estimator: 0 (default) = four launches (LayerNorm, q projection, attention, output
- * projection + residual), 1 = one fused launch per block (16-bit modes, contexts of <= 128 keys).  Same result up to the
- * rounding of the 16-bit intermediates (tests/test_gpu_xattn.py); the fused form is the slower one at batch 128 as measured in
- * round 1 and stays opt-in. */
-int stn_set_fused_xattn(stn_handle* h, int on);
 /* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
- * activation never leaves the registers (bf16 engines, block widths 256 / 384 / 512; other shapes keep the two GEMM launches).
+ * activation never leaves the registers (bf16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip
+ * idle while each still streams both weight matrices; other shapes keep the two GEMM launches).
  * Bit mask over the stages: 1 = vocoder, 2 = vector estimator, 4 = text encoder / duration predictor; 0 = never.  The default
  * is the set of stages where it measured faster on MI355X.  Same result as the two launches up to fp32
  * summation order (tests/test_gpu_ffn.py). */

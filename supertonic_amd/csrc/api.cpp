@@ -248,7 +248,6 @@ int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_m
 int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows() : 0; }
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
-int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_xattn(on != 0); }) }
 int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 7, "stage mask must be in 0..7"); h->eng->set_fused_ffn(mask); }) }
 int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }
 int64_t stn_graph_replays(const stn_handle* h) { return h ? h->eng->graph_replays() : 0; }

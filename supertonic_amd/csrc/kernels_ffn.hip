@@ -135,7 +135,24 @@ void launch_repack_frag_acc(hipStream_t s, const void* W, int N, int K, void* Wf
                 static_cast<uint16_t*>(Wf));
 }
 
-void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf);  // kernels_xattn.hip
+// W1 [N = I][K = C] row-major 16-bit -> phase-1 A fragments: lane (lr, lh) of hidden tile T, k-step ks holds
+// W[32T + lr][16ks + 8lh .. +8]; the 64 x 16 bytes of one MFMA operand are one contiguous KiB at ((T * K/16 + ks) * 64 + lane) * 16
+__global__ void repack_frag_kernel(const uint16_t* __restrict__ W, int N, int K, uint16_t* __restrict__ Wf) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte piece each
+    const int NKS = K / 16;
+    if (idx >= (int64_t)(N / 32) * NKS * 64) return;
+    const int lane = (int)(idx & 63);
+    const int64_t blk = idx >> 6;
+    const int ks = (int)(blk % NKS), T = (int)(blk / NKS);
+    const int lr = lane & 31, lh = lane >> 5;
+    reinterpret_cast<uint4*>(Wf)[idx] = *reinterpret_cast<const uint4*>(W + (size_t)(T * 32 + lr) * K + ks * 16 + lh * 8);
+}
+
+void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf) {
+    if (N % 32 || K % 16) throw std::invalid_argument("launch_repack_frag: N % 32 and K % 16 must be 0");
+    const int64_t n = (int64_t)(N / 32) * (K / 16) * 64;
+    STN_KLAUNCH(repack_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const uint16_t*>(W), N, K, static_cast<uint16_t*>(Wf));
+}
 
 void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq) {
     if (C % 64 || I % 64) throw std::invalid_argument("launch_ffn_pack: C % 64 and I % 64 must be 0");
