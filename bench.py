@@ -311,6 +311,25 @@ def main():
             out["single_utterance"] = single_utterance(eng, arch, up, args)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(arch, texts, ids, mask, sttl, sdp, durs, args)
+        log_path = os.environ.get("STN_LAUNCH_LOG")
+        if world == 1 and log_path:
+            # profiler runs (tools/profile_round.sh): the LAST step of the process is one fully tagged step of the bench batch,
+            # and its (family, kernel) sequence is written out for tools/pmc_families.py to align rocprofv3's dispatch rows with
+            eng.batch_upload(ids, mask, sttl, sdp, duration_override=durs, utt_ids=mine)
+            eng.set_graph_mode(False)
+            eng.batch_run(args.total_step, args.speed, 1234)
+            eng.sync()
+            eng.profile_filter(None)
+            eng.profile_sample(1)
+            eng.profile_enable(True)
+            eng.launch_log_enable(True)
+            eng.profile_reset()
+            eng.batch_run(args.total_step, args.speed, 1234)
+            eng.sync()
+            with open(log_path, "w") as f:
+                json.dump({"entries": eng.launch_log()}, f)
+            eng.launch_log_enable(False)
+            eng.profile_enable(False)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -321,7 +340,7 @@ def main():
 
 def _pmc_traffic(kernel):
     """(entry, stale): HBM bytes per launch of the dominant kernel from an offline `rocprofv3 --pmc` pass of this same command
-    (profiles/pmc_traffic.json, written by tools/pmc_summary.py), and whether that pass was taken on other kernel sources than
+    (profiles/pmc_traffic.json, written by tools/pmc_families.py), and whether that pass was taken on other kernel sources than
     the tree's (the file records tools/src_hash.py's hash); (None, False) until such a pass exists."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
@@ -336,7 +355,7 @@ def _pmc_traffic(kernel):
 
 
 def _pmc_mfma(kernel):
-    """Matrix-pipe utilisation of the dominant kernel from the committed PMC pass (tools/pmc_mfma.py); None if absent."""
+    """Matrix-pipe utilisation of the dominant kernel from the committed PMC pass (tools/pmc_families.py); None if absent."""
     p = os.path.join(ROOT, "profiles", "mfma_util.json")
     if os.path.exists(p):
         try:

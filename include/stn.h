@@ -169,6 +169,11 @@ int stn_profile_filter(stn_handle* h, const char* family_or_null);
 /* time only every n-th matching launch (n >= 1): a launch that carries events does not overlap its neighbours on the stream
    (~4 us each), so a timed region samples its dominant family instead of fencing every launch of it */
 int stn_profile_sample(stn_handle* h, int every);
+/* Launch log for profiler runs: while on (and profiling enabled) every kernel launch of this thread's engine calls is recorded
+   as "family\tkernel\n" in dispatch order (family "-" outside a timed family); stn_launch_log returns the bytes needed and fills
+   `out` when it fits.  tools/pmc_families.py aligns rocprofv3's per-dispatch rows with it.  Cleared by stn_profile_reset. */
+int stn_launch_log_enable(stn_handle* h, int on);
+int64_t stn_launch_log(stn_handle* h, char* out, size_t cap);
 /* number of kernel families seen; then per index: name, total ms, launches, algorithmic flops and bytes */
 int stn_profile_count(stn_handle* h);
 int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,

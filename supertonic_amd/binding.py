@@ -87,6 +87,9 @@ def load():
     L.stn_batch_copy_pcm16_device.argtypes = [vp, vp, ctypes.c_int64]
     L.stn_profile_filter.argtypes = [vp, ctypes.c_char_p]
     L.stn_profile_sample.argtypes = [vp, ci]
+    L.stn_launch_log_enable.argtypes = [vp, ci]
+    L.stn_launch_log.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    L.stn_launch_log.restype = ctypes.c_int64
     L.stn_profile_enable.argtypes = [vp, ci]
     L.stn_profile_reset.argtypes = [vp]
     L.stn_profile_count.argtypes = [vp]
@@ -236,6 +239,7 @@ class Engine:
         """K4 stage mask: 1 vocoder, 2 vector estimator, 4 text encoder / duration predictor (0 = two GEMM launches everywhere)."""
         self._ck(self._lib.stn_set_fused_ffn(self._h, int(mask)))
 
+    @property
     def vo_rows(self):
         return self._lib.stn_batch_vo_rows(self._h)
 
@@ -330,6 +334,18 @@ class Engine:
 
     def profile_filter(self, family=None):
         self._ck(self._lib.stn_profile_filter(self._h, family.encode() if family else None))
+
+    def launch_log_enable(self, on=True):
+        self._ck(self._lib.stn_launch_log_enable(self._h, int(bool(on))))
+
+    def launch_log(self):
+        """[(family, kernel)] of every launch since the last profile_reset (profiling on, log enabled), in dispatch order."""
+        n = self._lib.stn_launch_log(self._h, None, 0)
+        if n < 0:
+            self._ck(int(n))
+        buf = ctypes.create_string_buffer(int(n) + 1)
+        self._lib.stn_launch_log(self._h, buf, int(n) + 1)
+        return [tuple(l.split("\t")) for l in buf.value.decode().splitlines()]
 
     def profile_sample(self, every=1):
         self._ck(self._lib.stn_profile_sample(self._h, int(every)))

@@ -296,6 +296,15 @@ int stn_batch_copy_wav_device(stn_handle* h, void* dst, int64_t stride) {
 }
 
 int stn_profile_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->profile_enable(on != 0); }) }
+int stn_launch_log_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->launch_log_enable(on != 0); }) }
+int64_t stn_launch_log(stn_handle* h, char* out, size_t cap) {
+    if (!h) return STN_ERR_INVALID;
+    try {
+        const std::string s = h->eng->launch_log();
+        if (out && cap > s.size()) std::memcpy(out, s.c_str(), s.size() + 1);
+        return (int64_t)s.size();
+    } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_STATE; }
+}
 int stn_profile_sample(stn_handle* h, int every) { STN_TRY(h, { h->eng->profile_sample(every); }) }
 int stn_profile_filter(stn_handle* h, const char* fam) { STN_TRY(h, { h->eng->profile_filter(fam ? fam : ""); }) }
 int stn_profile_reset(stn_handle* h) { STN_TRY(h, { h->eng->profile_reset(); h->prof.clear(); }) }

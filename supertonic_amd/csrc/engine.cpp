@@ -410,6 +410,7 @@ void Engine::prof_begin(const char* tag, double flops, double bytes) {
     prof_active_ = false;
     if (!prof_on_ || spans_.size() > 200000) return;
     std::string full = std::string(stage_) + "." + tag;
+    if (g_launch_log.on) { log_family_ = full; g_launch_log.family = log_family_.c_str(); }
     if (!prof_filter_.empty() && full != prof_filter_) return;
     if (prof_every_ > 1 && (prof_seen_++ % prof_every_) != 0) return;  // sampled: a launch that carries events does not overlap its neighbours
     ProfSpan sp;
@@ -432,6 +433,7 @@ void Engine::prof_begin(const char* tag, double flops, double bytes) {
     prof_active_ = true;
 }
 void Engine::prof_end() {
+    g_launch_log.family = "-";
     if (!prof_active_) return;
     if (g_launch_ev.start) {  // nothing was launched (empty problem): drop the span
         g_launch_ev = LaunchEvents{};
@@ -446,6 +448,21 @@ void Engine::profile_reset() {
     // (cached graphs stay: a shape is only ever captured with profiling off, so no graph holds a pooled event)
     for (auto& sp : spans_) { ev_pool_.push_back(sp.a); ev_pool_.push_back(sp.b); }
     spans_.clear();
+    g_launch_log.entries.clear();
+}
+void Engine::launch_log_enable(bool on) { g_launch_log.on = on; g_launch_log.family = "-"; g_launch_log.entries.clear(); }
+std::string Engine::launch_log() const {
+    std::string out;
+    for (const auto& e : g_launch_log.entries) {
+        // kernel expression as written at the launch site: "(name<...>)" or "name" -> name
+        std::string k = e.second;
+        size_t b = 0;
+        while (b < k.size() && (k[b] == '(' || k[b] == ' ' || k[b] == '&')) ++b;
+        size_t en = b;
+        while (en < k.size() && (isalnum((unsigned char)k[en]) || k[en] == '_' || k[en] == ':')) ++en;
+        out += e.first + "\t" + k.substr(b, en - b) + "\n";
+    }
+    return out;
 }
 std::vector<std::pair<std::string, KernelStat>> Engine::profile_collect() {
     sync();
@@ -510,7 +527,9 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     // ... where it pays: a workgroup streams both weight matrices whatever its share of the rows, so below ~half a chip of
     // 128-row workgroups the two tiled launches win (tools/ffn_bench.py sweep, C = 512: 16384 rows 108 vs 107 us, 20480 rows
     // 116 vs 141 us, 294 rows = one utterance 102 vs 29 us)
-    if ((fused_ffn_ & stage_bit) && M >= ffn_min_rows_ && fw != ffn_w_.end() && ffn_fused_supported(dt_, C, hid) && M * C * 2 < 0x7FFFFFFFll) {
+    // (the vocoder decides on its DENSE frame count: a run that skips position-independent padding rows must take the same kernel
+    // as the dense run it is bit-identical to)
+    if ((fused_ffn_ & stage_bit) && (ffn_gate_rows_ > 0 ? ffn_gate_rows_ : M) >= ffn_min_rows_ && fw != ffn_w_.end() && ffn_fused_supported(dt_, C, hid) && M * C * 2 < 0x7FFFFFFFll) {
         FfnArgs fa;
         fa.xn = xn; fa.ldx = C; fa.wseq = fw->second.wseq; fa.b1 = p.pw1.b; fa.b2 = p.pw2.b; fa.gamma = p.gamma;
         fa.x = x; fa.ldo = C; fa.M = (int)M; fa.I = hid; fa.rowvec = rowvec; fa.rv_ld = rv_ld;
@@ -875,6 +894,7 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
     const bool packed = vlen && vrows > 0 && is_half(dt_) && B <= 1024 && dwconv_ln_supports_packed(C, a.vo_kernel);
     if (valid && !packed) throw std::runtime_error("trimmed vocoder needs the packed bf16 path");
     const int64_t M = packed ? (int64_t)vrows : (int64_t)B * T;
+    ffn_gate_rows_ = valid ? (int64_t)B * T : 0;
     const Arena::Mark mk = ar_.mark();
     Ragged rg;
     if (packed) {
@@ -903,6 +923,7 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
     for (int i = 0; i < a.vo_blocks; ++i)
         convnext(convnext_w("vo.blk" + std::to_string(i)), x, B, T, C, a.vo_hidden, a.vo_kernel, a.vo_dilations[i],
                  packed ? vlen : nullptr, packed ? nullptr : vlen, nullptr, 0, rgp);
+    ffn_gate_rows_ = 0;
     void* xn = act_alloc(M * C);
     const LNorm ln = lnorm("vo.out_ln");
     launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);

@@ -185,6 +185,8 @@ class Engine {
 
     // ---- profiling (hipEvent pairs around launches of one kernel family, on this stream) ----------------
     void profile_enable(bool on) { if (on != prof_on_) profile_reset(); prof_on_ = on; }
+    void launch_log_enable(bool on);   // record (family, kernel) of every launch while profiling is on (this thread's engine calls)
+    std::string launch_log() const;    // "family\tkernel\n" per launch since the last profile_reset, dispatch order
     void profile_sample(int every) { prof_every_ = every < 1 ? 1 : every; prof_seen_ = 0; }  // time every n-th matching launch only
     void profile_filter(const std::string& family) { if (family != prof_filter_) profile_reset(); prof_filter_ = family; }  // "" = every family
     void profile_reset();
@@ -245,6 +247,7 @@ class Engine {
     hipStream_t s_ = nullptr, own_s_ = nullptr;
     const char* stage_ = "";
     std::string prof_filter_;
+    std::string log_family_;
     int prof_every_ = 1;
     uint64_t prof_seen_ = 0;
     bool prof_active_ = false;
@@ -283,6 +286,7 @@ class Engine {
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
     bool nt_hints_ = true;
+    int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int fused_ffn_ = 1;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 
 #include <stdexcept>
+#include <utility>
+#include <vector>
 #include <string>
 
 namespace stn {
@@ -19,8 +21,19 @@ namespace stn {
 // instead of being bracketed by hipEventRecord barriers that add the dispatch boundary to the span.
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
 inline thread_local LaunchEvents g_launch_ev;
+// Launch log (profiling runs only): kernel expression + the kernel family the engine was in, one entry per launch in dispatch
+// order — what tools/pmc_families.py aligns rocprofv3's per-dispatch rows with, so that counters are attributed to families
+// by position instead of by guessing from template arguments and grid sizes.
+struct LaunchLog {
+    bool on = false;
+    const char* family = "-";
+    std::vector<std::pair<std::string, const char*>> entries;  // (family, kernel expression)
+    void add(const char* kexpr) { if (entries.size() < 200000) entries.emplace_back(family, kexpr); }
+};
+inline thread_local LaunchLog g_launch_log;
 #define STN_KLAUNCH(kernel, grid, block, lds, stream, ...)                                                              \
     do {                                                                                                                \
+        if (::stn::g_launch_log.on) ::stn::g_launch_log.add(#kernel);                                                   \
         if (::stn::g_launch_ev.start) {                                                                                 \
             const ::stn::LaunchEvents ev_ = ::stn::g_launch_ev;                                                         \
             ::stn::g_launch_ev = ::stn::LaunchEvents{};                                                                 \

@@ -829,7 +829,8 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
     if (dtype == F32) {
         // fp32 MFMA is 1/16 of the bf16 rate: always compute-bound, tile choice only has to keep the CUs busy
         if (K % 32) return false;
-        if (M <= 64) launch_tiled<MODE, 64, 64, 2, 2, 4, 32, 4>(s, A, lda, W, ldw, M, N, K, e);
+        // (a narrow N leaves few 128-wide tiles: the duration predictor's 9 k x 128 pw2 is 71 of them on 256 CUs)
+        if (M <= 64 || (long)((M + 127) / 128) * ((N + 127) / 128) < 160) launch_tiled<MODE, 64, 64, 2, 2, 4, 32, 4>(s, A, lda, W, ldw, M, N, K, e);
         else launch_tiled<MODE, 128, 128, 2, 2, 3, 32, 4>(s, A, lda, W, ldw, M, N, K, e);
         return true;
     }
