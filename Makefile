@@ -7,7 +7,7 @@ CSRC    := supertonic_amd/csrc
 # five instructions).  The compiler forms such ops freely, so the feature is switched off for the
 # device pass (the host pass prints "not a recognized feature", which is expected).
 NOPKF32 := -Xclang -target-feature -Xclang -packed-fp32-ops
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude $(NOPKF32)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude $(NOPKF32) $(EXTRA)
 KERNELS := $(CSRC)/kernels_gemm.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_attn.hip $(CSRC)/kernels_ffn.hip
 HOSTSRC := $(CSRC)/engine.cpp $(CSRC)/api.cpp $(wildcard $(CSRC)/host/*.cpp)
 OBJS    := $(patsubst %.hip,build/%.o,$(KERNELS)) $(patsubst %.cpp,build/%.o,$(HOSTSRC))

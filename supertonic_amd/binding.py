@@ -135,6 +135,7 @@ class Engine:
             self._h = None
             raise StnError(rc, msg)
         self.dtype = _DTYPES[dtype]
+        self.device = device
         self.arch = None
 
     def close(self):

@@ -50,7 +50,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #undef STN_V_NODMA
 #undef STN_V_NOGELU
 #undef STN_V_EARLYRD
-// timing-only variants (wrong results): which part of a block costs what
+// timing-only variants (wrong results; each drops one ingredient of a block to see what it costs — DESIGN.md section 5d).
+// Not part of the product build: `make EXTRA=-DSTN_FFN_VARIANTS` compiles them in and STN_FFN_VAR=<1..5> selects one.
+#ifdef STN_FFN_VARIANTS
 namespace v_nodma {
 #define STN_V_NODMA 1
 #define STN_V_NOGELU 0
@@ -111,6 +113,8 @@ namespace v_bare {
 #undef STN_V_NOGELU
 #undef STN_V_EARLYRD
 }
+
+#endif
 
 // W2 [N = C][K = I] row-major 16-bit -> phase-2 A fragments in the accumulator-operand k order:
 //   piece ((t * C/32 + nt) * 2 + s), lane (r, hf), element j  <-  W2[32nt + r][32t + 16s + 8(j>>2) + 4hf + (j&3)]
@@ -181,8 +185,9 @@ static void launch_ffn_t(hipStream_t s, const FfnArgs& a) {
     if (attr_once.need())
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024), "hipFuncSetAttribute(ffn_fused)");
-    static const int var = [] { const char* e = getenv("STN_FFN_VAR"); return e ? atoi(e) : 0; }();
     const dim3 grid((unsigned)((a.M + 127) / 128));
+#ifdef STN_FFN_VARIANTS
+    static const int var = [] { const char* e = getenv("STN_FFN_VAR"); return e ? atoi(e) : 0; }();
     auto go = [&](auto kern) {
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(ffn_fused variant)");
         STN_KLAUNCH(kern, grid, dim3(256), lds, s, a);
@@ -192,6 +197,7 @@ static void launch_ffn_t(hipStream_t s, const FfnArgs& a) {
     if (var == 3) { go(&v_earlyrd::ffn_fused_kernel<C>); return; }
     if (var == 4) { go(&v_bare::ffn_fused_kernel<C>); return; }
     if (var == 5) { go(&v_nord::ffn_fused_kernel<C>); return; }
+#endif
     STN_KLAUNCH((ffn_fused_kernel<C>), grid, dim3(256), lds, s, a);
 }
 

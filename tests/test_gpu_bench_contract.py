@@ -38,10 +38,14 @@ def test_bench_json_line_contract():
     # host-to-host rate beside the device-resident one (the contract of _infer's return, cpp/helper.cpp:674-682)
     for k in ("value_host", "ms_per_step_host", "p50_latency_host_ms", "host_loop"):
         assert k in d, k
-    assert 0 < d["value_host"] <= d["value"] * 1.02 and d["ms_per_step_host"] >= d["ms_per_step"] * 0.98
+    # the host loop keeps two batches in flight (two engine handles), `value` runs one at a time: the host-to-host rate is bounded
+    # by the resident two-in-flight rate, not by `value`
+    t2 = d["two_in_flight"]
+    assert d["config"]["in_flight_batches"] == 1 and t2["value"] > 0.9 * d["value"]
+    assert 0 < d["value_host"] <= t2["value"] * 1.03 and d["ms_per_step_host"] >= t2["ms_per_step"] * 0.97
     assert abs(d["value_host"] - d["config"]["audio_sec_per_step"] / (d["ms_per_step_host"] * 1e-3)) / d["value_host"] < 1e-3
     pc = d["host_loop"]["pcie_bytes_per_step"]
-    assert pc["d2h"] > 10e6 and pc["h2d"] > 1e6 and d["p50_latency_host_ms"] >= d["ms_per_step_host"] * 0.9
+    assert pc["d2h"] > 10e6 and pc["h2d"] > 1e6 and d["p50_latency_host_ms"] >= d["ms_per_step"] * 0.98
     assert "forced" in d["config"]["durations"]
     su = d["single_utterance"]
     assert su["f32"]["p50_ms"] > 0 and su["bf16"]["p50_ms"] > 0 and su["bf16"]["p50_ms"] < su["f32"]["p50_ms"]
