@@ -104,6 +104,8 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     STN_HIP(hipSetDevice(device));
     STN_HIP(hipStreamCreateWithFlags(&own_s_, hipStreamNonBlocking));
     s_ = own_s_;
+    STN_HIP(hipStreamCreateWithFlags(&dp_s_, hipStreamNonBlocking));
+    if (const char* p = getenv("STN_DP_STREAM")) if (atoi(p) == 0) { (void)hipStreamDestroy(dp_s_); dp_s_ = nullptr; }  // A/B switch
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
@@ -140,6 +142,7 @@ void Engine::free_weights() {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (s_) (void)hipStreamSynchronize(s_);
+    if (dp_s_) (void)hipStreamSynchronize(dp_s_);
     free_weights();
     for (void* p : batch_owned_) (void)hipFree(p);
     for (void* p : batch_retired_) (void)hipFree(p);
@@ -160,6 +163,7 @@ Engine::~Engine() {
     }
     if (copy_s_) (void)hipStreamDestroy(copy_s_);
     if (own_s_) (void)hipStreamDestroy(own_s_);
+    if (dp_s_) (void)hipStreamDestroy(dp_s_);
 }
 
 DevTensor& Engine::tensor(const std::string& name) {
@@ -1130,13 +1134,21 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     Ragged trg;
     const bool tpk = packed_text_ok(B) && b.trows > 0;
     if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
-    duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
     std::vector<float> dur(B);
-    if (b.have_override) {
-        dur = b.h_dur;  // known on the host: no device->host read, no sync
-    } else {
-        STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
-        sync();  // the one host round trip: L = f(max duration) sizes every later buffer
+    {
+        // on the side stream, with the side workspace (see dp_s_): swap them in for the duration of the stage
+        struct Side {
+            Engine& e; bool on;
+            Side(Engine& e_) : e(e_), on(e_.dp_s_ != nullptr) { if (on) { std::swap(e.s_, e.dp_s_); e.ar_.swap(e.dp_ar_); e.ar_.reset(); } }
+            ~Side() { if (on) { std::swap(e.s_, e.dp_s_); e.ar_.swap(e.dp_ar_); } }
+        } side(*this);
+        duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
+        if (b.have_override) {
+            dur = b.h_dur;  // known on the host: no device->host read, no sync
+        } else {
+            STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
+            STN_HIP(hipStreamSynchronize(s_));  // the one host round trip (this stage's stream only): L = f(max duration) sizes every later buffer
+        }
     }
     for (float& d : dur) d /= speed;  // cpp/helper.cpp:529-531
     int L = 0;

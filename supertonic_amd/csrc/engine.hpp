@@ -44,7 +44,11 @@ struct Attn { LNorm ln; Linear q, kv, qkv, o; };  // kv = [Wk; Wv] rows, qkv = [
 class Arena {
    public:
     struct Mark { size_t chunk, off; };
+    Arena() = default;
+    Arena(const Arena&) = delete;             // owns device memory: a copy would free it twice
+    Arena& operator=(const Arena&) = delete;
     ~Arena();
+    void swap(Arena& o) { chunks_.swap(o.chunks_); std::swap(cur_, o.cur_); std::swap(off_, o.off_); }
     void* alloc(size_t bytes);
     Mark mark() const { return {cur_, off_}; }
     void release(Mark m) { cur_ = m.chunk; off_ = m.off; }
@@ -76,7 +80,7 @@ class Engine {
     int64_t param_count() const { return params_; }
     int dtype() const { return dt_; }
     hipStream_t stream() const { return s_; }
-    void sync() { STN_HIP(hipStreamSynchronize(s_)); }
+    void sync() { STN_HIP(hipStreamSynchronize(s_)); if (dp_s_) STN_HIP(hipStreamSynchronize(dp_s_)); }
     // run on a caller-owned stream (e.g. torch's current stream, so RCCL ops order after the engine's kernels);
     // nullptr returns to the engine's own stream
     void set_stream(hipStream_t s);
@@ -286,6 +290,11 @@ class Engine {
     bool vo_ragged_ = false;
     bool packed_ve_ = true;
     bool nt_hints_ = true;
+    // The duration predictor of stn_batch_run depends on the uploaded inputs only (not on the previous batch, not on the text
+    // encoder): it runs on its own stream with its own workspace, beside the text encoder of the same batch and, in back-to-back
+    // runs, beside the tail of the previous one.  Everything that overwrites its inputs goes through sync(), which waits for both.
+    hipStream_t dp_s_ = nullptr;
+    Arena dp_ar_;
     int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int fused_ffn_ = 1;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
