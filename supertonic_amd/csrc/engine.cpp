@@ -105,6 +105,9 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     STN_HIP(hipStreamCreateWithFlags(&own_s_, hipStreamNonBlocking));
     s_ = own_s_;
     STN_HIP(hipStreamCreateWithFlags(&dp_s_, hipStreamNonBlocking));
+    STN_HIP(hipEventCreateWithFlags(&ev_te_, hipEventDisableTiming));
+    STN_HIP(hipEventCreateWithFlags(&ev_copied_, hipEventDisableTiming));
+    STN_HIP(hipEventCreateWithFlags(&ev_dp_, hipEventDisableTiming));
     if (const char* p = getenv("STN_DP_STREAM")) if (atoi(p) == 0) { (void)hipStreamDestroy(dp_s_); dp_s_ = nullptr; }  // A/B switch
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
@@ -164,6 +167,9 @@ Engine::~Engine() {
     if (copy_s_) (void)hipStreamDestroy(copy_s_);
     if (own_s_) (void)hipStreamDestroy(own_s_);
     if (dp_s_) (void)hipStreamDestroy(dp_s_);
+    if (ev_te_) (void)hipEventDestroy(ev_te_);
+    if (ev_copied_) (void)hipEventDestroy(ev_copied_);
+    if (ev_dp_) (void)hipEventDestroy(ev_dp_);
 }
 
 DevTensor& Engine::tensor(const std::string& name) {
@@ -1135,21 +1141,34 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     const bool tpk = packed_text_ok(B) && b.trows > 0;
     if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
     std::vector<float> dur(B);
+    // the text rows: persistent, grow-only buffers (a reallocation bumps b.gen, which every graph key holds)
+    const size_t text_bytes = (size_t)(tpk ? (int64_t)b.trows : (int64_t)B * Lt) * a.te_out_dim * (is_half(dt_) ? 2 : 4);
+    ensure(b.text_side, b.text_side_cap, text_bytes);
+    ensure(b.text_rows, b.text_cap, text_bytes);
     {
-        // on the side stream, with the side workspace (see dp_s_): swap them in for the duration of the stage
+        // on the side stream, with the side workspace (see dp_s_): swap them in for the duration of the two text stages
         struct Side {
             Engine& e; bool on;
             Side(Engine& e_) : e(e_), on(e_.dp_s_ != nullptr) { if (on) { std::swap(e.s_, e.dp_s_); e.ar_.swap(e.dp_ar_); e.ar_.reset(); } }
             ~Side() { if (on) { std::swap(e.s_, e.dp_s_); e.ar_.swap(e.dp_ar_); } }
         } side(*this);
         duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
-        if (b.have_override) {
-            dur = b.h_dur;  // known on the host: no device->host read, no sync
-        } else {
+        if (!b.have_override) {
             STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
-            STN_HIP(hipStreamSynchronize(s_));  // the one host round trip (this stage's stream only): L = f(max duration) sizes every later buffer
+            STN_HIP(hipEventRecord(ev_dp_, s_));
         }
+        // 2. text encoder -> context rows (act dtype), once the previous run has taken its copy of them
+        if (side.on && copied_valid_) STN_HIP(hipStreamWaitEvent(s_, ev_copied_, 0));
+        text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, b.text_side, tpk ? &trg : nullptr);
+        STN_HIP(hipEventRecord(ev_te_, s_));
+        if (b.have_override) dur = b.h_dur;  // known on the host: no device->host read, no sync
+        else STN_HIP(hipEventSynchronize(ev_dp_));  // the one host round trip (the predictor only): L = f(max duration) sizes every later buffer
     }
+    // head of the main pipeline: take this run's text rows (everything captured below reads b.text_rows)
+    if (dp_s_) STN_HIP(hipStreamWaitEvent(s_, ev_te_, 0));
+    STN_HIP(hipMemcpyAsync(b.text_rows, b.text_side, text_bytes, hipMemcpyDeviceToDevice, s_));
+    STN_HIP(hipEventRecord(ev_copied_, s_));
+    copied_valid_ = true;
     for (float& d : dur) d /= speed;  // cpp/helper.cpp:529-531
     int L = 0;
     latent_geometry(a, dur, L, b.h_llen);
@@ -1257,13 +1276,12 @@ void Engine::enqueue_after_duration(int total_step) {
     const size_t nx = (size_t)B * D * L;
     STN_HIP(hipMemcpyAsync(b.llen, pin_llen_, sizeof(int) * B, hipMemcpyHostToDevice, s_));
     STN_HIP(hipMemcpyAsync(seed_dev_, pin_seed_, sizeof(unsigned long long), hipMemcpyHostToDevice, s_));
-    // 2. text encoder -> context rows (act dtype)
+    // 2. (the text encoder ran on the side stream: batch_run) its rows
     Ragged trg;
     const bool tpk = packed_text_ok(B) && b.trows > 0;
     if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
     const Ragged* trgp = tpk ? &trg : nullptr;
-    void* text_rows = act_alloc((tpk ? (int64_t)b.trows : (int64_t)B * Lt) * a.te_out_dim);
-    text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, text_rows, trgp);
+    void* text_rows = b.text_rows;
     // 3. initial latent
     if (b.have_noise) {
         STN_HIP(hipMemcpyAsync(b.xt[0], b.noise, nx * 4, hipMemcpyDeviceToDevice, s_));

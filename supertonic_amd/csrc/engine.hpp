@@ -144,6 +144,10 @@ class Engine {
         float* xt[2] = {nullptr, nullptr}; size_t xt_cap[2] = {0, 0};
         float* wav = nullptr; size_t wav_cap = 0;        // [B, L*cs]
         int16_t* pcm = nullptr; size_t pcm_cap = 0;      // [B, L*cs] int16 (on demand)
+        // text-encoder output rows: written on the side stream (text_side), copied at the head of the main pipeline into the
+        // buffer the captured graphs read (text_rows) — so the encoder of run i+1 can work while run i still reads its rows
+        unsigned char* text_side = nullptr; size_t text_side_cap = 0;
+        unsigned char* text_rows = nullptr; size_t text_cap = 0;
         int* toff = nullptr; size_t toff_cap = 0;       // packed text rows: first row of each utterance [B+1]
         int trows = 0;                                   // sum of the text lengths
         uint64_t gen = 0;
@@ -295,6 +299,11 @@ class Engine {
     // runs, beside the tail of the previous one.  Everything that overwrites its inputs goes through sync(), which waits for both.
     hipStream_t dp_s_ = nullptr;
     Arena dp_ar_;
+    // The text encoder depends on the uploaded inputs only as well: it runs on the same side stream (after the predictor) into
+    // text_side; the main stream waits for ev_te_, copies the rows into text_rows (what the graphs read) and records ev_copied_,
+    // which the side stream waits for before the NEXT run's encoder overwrites text_side (prefetch depth: one run).
+    hipEvent_t ev_te_ = nullptr, ev_copied_ = nullptr, ev_dp_ = nullptr;
+    bool copied_valid_ = false;
     int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int fused_ffn_ = 1;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
