@@ -143,6 +143,9 @@ int stn_batch_fetch_pcm16(stn_handle* h, int16_t* pcm, size_t capacity_samples, 
  * the host-to-host path of _infer's contract (host inputs in, host waveform out: cpp/helper.cpp:674-682) at full overlap. */
 int stn_batch_fetch_pcm16_begin(stn_handle* h, int slot /* 0 or 1 */);
 int stn_batch_fetch_pcm16_end(stn_handle* h, int slot, const int16_t** pcm, size_t* n_samples, float* duration_or_null);
+/* the batch a slot holds (fixed at its _begin; the resident batch may have changed since): utterances, samples per utterance;
+ * `duration_or_null` of _end takes B floats */
+int stn_batch_fetch_slot_dims(stn_handle* h, int slot, int* B, int64_t* samples_per_utt);
 /* page-locked host memory for the caller's input buffers (ids, masks, styles): uploads from it are asynchronous DMA instead of a
  * staged copy.  NULL on failure. */
 void* stn_host_alloc_pinned(size_t bytes);

@@ -76,6 +76,7 @@ def load():
     L.stn_batch_fetch_latent.argtypes = [vp, _f32p]
     L.stn_batch_fetch_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]
     L.stn_batch_fetch_pcm16_begin.argtypes = [vp, ci]
+    L.stn_batch_fetch_slot_dims.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_int64)]
     L.stn_batch_fetch_pcm16_end.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), vp]
     L.stn_host_alloc_pinned.restype = vp
     L.stn_host_alloc_pinned.argtypes = [ctypes.c_size_t]
@@ -259,9 +260,10 @@ class Engine:
     def fetch_pcm16_end(self, slot, copy=True):
         """Wait for the slot's copy -> (pcm [B, W] int16, duration [B]).  copy=False returns a view of the handle's pinned buffer
         (valid until the slot's next fetch_pcm16_begin)."""
-        B, L, W = self.batch_dims()
+        B, W = ctypes.c_int(), ctypes.c_int64()
+        self._ck(self._lib.stn_batch_fetch_slot_dims(self._h, int(slot), ctypes.byref(B), ctypes.byref(W)))  # the slot's batch, not the resident one
         ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
-        dur = np.empty(B, np.float32)
+        dur = np.empty(B.value, np.float32)
         self._ck(self._lib.stn_batch_fetch_pcm16_end(self._h, int(slot), ctypes.byref(ptr), ctypes.byref(n), dur.ctypes.data))
         arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int16)), shape=(n.value,))
         rows = n.value // max(dur.size, 1)

@@ -267,6 +267,15 @@ int stn_batch_fetch(stn_handle* h, float* wav, size_t cap, float* duration) {
 int stn_batch_fetch_pcm16(stn_handle* h, int16_t* pcm, size_t cap, float* duration) {
     STN_TRY(h, { need(pcm && h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_pcm16(pcm, cap, duration); })
 }
+int stn_batch_fetch_slot_dims(stn_handle* h, int slot, int* B, int64_t* W) {
+    if (!h) return STN_ERR_INVALID;
+    if (slot < 0 || slot > 1) { h->err = "fetch slot must be 0 or 1"; return STN_ERR_INVALID; }
+    int b = 0; int64_t w = 0;
+    if (!h->eng->fetch_slot_dims(slot, &b, &w)) { h->err = "no fetch in flight on this slot"; return STN_ERR_STATE; }
+    if (B) *B = b;
+    if (W) *W = w;
+    return STN_OK;
+}
 int stn_batch_fetch_pcm16_begin(stn_handle* h, int slot) {
     STN_TRY(h, { need(h->eng->batch().B > 0 && h->eng->batch().L > 0, "no finished batch"); h->eng->batch_fetch_pcm16_begin(slot); })
 }

@@ -183,6 +183,12 @@ class Engine {
     // The same, pipelined: _begin converts into the device slot and starts its device->host copy on a second stream (the next
     // stn_batch_upload / stn_batch_run proceed meanwhile: the copy of batch i overlaps the synthesis of batch i+1); _end waits
     // for that copy and hands out the slot's pinned host buffer (valid until the slot's next _begin).  Two slots.
+    bool fetch_slot_dims(int slot, int* B, int64_t* W) const {
+        const FetchSlot& f = fetch_[slot];
+        if (!f.busy || f.dur.empty()) return false;
+        *B = (int)f.dur.size(); *W = (int64_t)(f.n / f.dur.size());
+        return true;
+    }
     void batch_fetch_pcm16_begin(int slot);
     void batch_fetch_pcm16_end(int slot, const int16_t** pcm, size_t* n, float* duration);
     void batch_fetch_latent(float* latent);  // final denoised latent [B,D,L] (tests)
