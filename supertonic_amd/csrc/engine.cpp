@@ -108,7 +108,11 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     STN_HIP(hipEventCreateWithFlags(&ev_te_, hipEventDisableTiming));
     STN_HIP(hipEventCreateWithFlags(&ev_copied_, hipEventDisableTiming));
     STN_HIP(hipEventCreateWithFlags(&ev_dp_, hipEventDisableTiming));
-    if (const char* p = getenv("STN_DP_STREAM")) if (atoi(p) == 0) { (void)hipStreamDestroy(dp_s_); dp_s_ = nullptr; }  // A/B switch
+    STN_HIP(hipStreamCreateWithFlags(&te_s_, hipStreamNonBlocking));
+    if (const char* p = getenv("STN_DP_STREAM")) if (atoi(p) == 0) {  // A/B switch: everything on the main stream
+        (void)hipStreamDestroy(dp_s_); dp_s_ = nullptr;
+        (void)hipStreamDestroy(te_s_); te_s_ = nullptr;
+    }
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
@@ -146,6 +150,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (s_) (void)hipStreamSynchronize(s_);
     if (dp_s_) (void)hipStreamSynchronize(dp_s_);
+    if (te_s_) (void)hipStreamSynchronize(te_s_);
     free_weights();
     for (void* p : batch_owned_) (void)hipFree(p);
     for (void* p : batch_retired_) (void)hipFree(p);
@@ -167,6 +172,7 @@ Engine::~Engine() {
     if (copy_s_) (void)hipStreamDestroy(copy_s_);
     if (own_s_) (void)hipStreamDestroy(own_s_);
     if (dp_s_) (void)hipStreamDestroy(dp_s_);
+    if (te_s_) (void)hipStreamDestroy(te_s_);
     if (ev_te_) (void)hipEventDestroy(ev_te_);
     if (ev_copied_) (void)hipEventDestroy(ev_copied_);
     if (ev_dp_) (void)hipEventDestroy(ev_dp_);
@@ -1146,26 +1152,31 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     ensure(b.text_side, b.text_side_cap, text_bytes);
     ensure(b.text_rows, b.text_cap, text_bytes);
     {
-        // on the side stream, with the side workspace (see dp_s_): swap them in for the duration of the two text stages
+        // on the side streams, each with its own workspace (see dp_s_): swapped in for the duration of a text stage
         struct Side {
-            Engine& e; bool on;
-            Side(Engine& e_) : e(e_), on(e_.dp_s_ != nullptr) { if (on) { std::swap(e.s_, e.dp_s_); e.ar_.swap(e.dp_ar_); e.ar_.reset(); } }
-            ~Side() { if (on) { std::swap(e.s_, e.dp_s_); e.ar_.swap(e.dp_ar_); } }
-        } side(*this);
-        duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
-        if (!b.have_override) {
-            STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
-            STN_HIP(hipEventRecord(ev_dp_, s_));
+            Engine& e; hipStream_t& s; Arena& ar; bool on;
+            Side(Engine& e_, hipStream_t& s_, Arena& ar_) : e(e_), s(s_), ar(ar_), on(s_ != nullptr) { if (on) { std::swap(e.s_, s); e.ar_.swap(ar); e.ar_.reset(); } }
+            ~Side() { if (on) { std::swap(e.s_, s); e.ar_.swap(ar); } }
+        };
+        {   // 2. text encoder -> context rows (act dtype), once the previous run has taken its copy of them
+            Side side(*this, te_s_, te_ar_);
+            if (side.on && copied_valid_) STN_HIP(hipStreamWaitEvent(s_, ev_copied_, 0));
+            text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, b.text_side, tpk ? &trg : nullptr);
+            STN_HIP(hipEventRecord(ev_te_, s_));
         }
-        // 2. text encoder -> context rows (act dtype), once the previous run has taken its copy of them
-        if (side.on && copied_valid_) STN_HIP(hipStreamWaitEvent(s_, ev_copied_, 0));
-        text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, b.text_side, tpk ? &trg : nullptr);
-        STN_HIP(hipEventRecord(ev_te_, s_));
+        {   // 1. duration predictor (always executed; its output may be overridden for shape control), beside the encoder
+            Side side(*this, dp_s_, dp_ar_);
+            duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
+            if (!b.have_override) {
+                STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
+                STN_HIP(hipEventRecord(ev_dp_, s_));
+            }
+        }
         if (b.have_override) dur = b.h_dur;  // known on the host: no device->host read, no sync
         else STN_HIP(hipEventSynchronize(ev_dp_));  // the one host round trip (the predictor only): L = f(max duration) sizes every later buffer
     }
     // head of the main pipeline: take this run's text rows (everything captured below reads b.text_rows)
-    if (dp_s_) STN_HIP(hipStreamWaitEvent(s_, ev_te_, 0));
+    if (te_s_) STN_HIP(hipStreamWaitEvent(s_, ev_te_, 0));
     STN_HIP(hipMemcpyAsync(b.text_rows, b.text_side, text_bytes, hipMemcpyDeviceToDevice, s_));
     STN_HIP(hipEventRecord(ev_copied_, s_));
     copied_valid_ = true;

@@ -80,7 +80,7 @@ class Engine {
     int64_t param_count() const { return params_; }
     int dtype() const { return dt_; }
     hipStream_t stream() const { return s_; }
-    void sync() { STN_HIP(hipStreamSynchronize(s_)); if (dp_s_) STN_HIP(hipStreamSynchronize(dp_s_)); }
+    void sync() { STN_HIP(hipStreamSynchronize(s_)); if (dp_s_) STN_HIP(hipStreamSynchronize(dp_s_)); if (te_s_) STN_HIP(hipStreamSynchronize(te_s_)); }
     // run on a caller-owned stream (e.g. torch's current stream, so RCCL ops order after the engine's kernels);
     // nullptr returns to the engine's own stream
     void set_stream(hipStream_t s);
@@ -303,8 +303,8 @@ class Engine {
     // The duration predictor of stn_batch_run depends on the uploaded inputs only (not on the previous batch, not on the text
     // encoder): it runs on its own stream with its own workspace, beside the text encoder of the same batch and, in back-to-back
     // runs, beside the tail of the previous one.  Everything that overwrites its inputs goes through sync(), which waits for both.
-    hipStream_t dp_s_ = nullptr;
-    Arena dp_ar_;
+    hipStream_t dp_s_ = nullptr, te_s_ = nullptr;
+    Arena dp_ar_, te_ar_;
     // The text encoder depends on the uploaded inputs only as well: it runs on the same side stream (after the predictor) into
     // text_side; the main stream waits for ev_te_, copies the rows into text_rows (what the graphs read) and records ev_copied_,
     // which the side stream waits for before the NEXT run's encoder overwrites text_side (prefetch depth: one run).
