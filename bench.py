@@ -462,11 +462,13 @@ def host_loop(eng, up, texts, sttl, sdp, durs, utt_ids, args, fence):
     del eng2
     h2d = int(p_ids.nbytes + p_mask.nbytes + p_ttl.nbytes + p_dp.nbytes + durs.nbytes + 8 * B)
     return {"elapsed": elapsed, "p50": round(float(np.median(lat)), 3), "elapsed_resident_two_in_flight": el2,
+            "in_flight_batches": 2,
             "text_frontend_ms_per_step": round(t_front[0] / args.steps * 1e3, 3),
             "pcie_bytes_per_step": {"h2d": h2d, "d2h": n_pcm * 2 + 4 * B},
             "note": "per batch: text -> ids (C++ frontend), upload from pinned memory, synthesis, int16 PCM into pinned host memory; the "
                     "device->host copy of batch i and the text frontend of batch i+1 (one worker thread) overlap the synthesis (stn_batch_fetch_pcm16_begin/_end); "
-                    "two engine handles alternate so that batch i+1 is uploaded and queued while batch i computes; "
+                    "two engine handles alternate so that batch i+1 is uploaded, queued AND STARTED while batch i computes (two batches in flight: this rate "
+                    "is bounded by `two_in_flight`, not by `value`, which runs one batch at a time); "
                     "every batch is tokenised anew; p50_latency_host_ms = one batch alone, nothing overlapped"}
 
 
