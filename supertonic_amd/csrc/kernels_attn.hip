@@ -189,6 +189,14 @@ __device__ __forceinline__ f32x16_t mfma_h(bf16x8_t a, bf16x8_t b, f32x16_t c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// In-kernel phase stamps of one workgroup (measurement builds only: make EXTRA=-DSTN_ATTN_STAMPS; tools/attn_phases.py)
+#ifdef STN_ATTN_STAMPS
+__device__ unsigned long long g_attn_ts[8];
+extern "C" void stn_dbg_attn_ts(unsigned long long* out) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_ts), sizeof(unsigned long long) * 8); }
+#define ATTN_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 5 && threadIdx.x == 0) g_attn_ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
 template <int DH, bool F16>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ q, int ldq,
                                                         const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     constexpr int HD2 = DH / 2;
     const float qmul = rsqrtf((float)DH) * 1.44269504088896340736f;
 
+    ATTN_STAMP(0);
     if (rope_mode >= 0) {
         for (int i = tid; i < HD2; i += 256) inv_rev[i] = __expf(-log_base * (float)(2 * i) / (float)DH) * 0.15915494309189535f;
         __syncthreads();
@@ -364,14 +373,18 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     };
 
     stage_rows(0, 0);
+    ATTN_STAMP(1);
     if (nch == 1) {  // the whole context fits one chunk: K is staged once and serves both passes
         stage_rows(1, 0);
+        ATTN_STAMP(2);
         stage_v(0);
         __syncthreads();
+        ATTN_STAMP(3);
         if (active) {
             load_q();
             pass_max(0);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
+            ATTN_STAMP(4);
             pass_pv(0);
         }
     } else {  // long contexts (up to ~320 text tokens): K streams through the chunk buffer twice, V once
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     if constexpr (DH == 32) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]));
     else if constexpr (DH == 64) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]), "+a"(oacc[1]));
     else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oacc[0]), "+a"(oacc[1]), "+a"(oacc[2]));
+    ATTN_STAMP(5);
     if (!active) return;
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = (nk > 0 && lsum > 0.f) ? 1.0f / lsum : 0.f;
@@ -415,6 +429,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
             for (int nd = 0; nd < DH / 32; ++nd) orow[nd * 32] = (uint16_t)pack_h2<F16>(oacc[nd][i] * invq, 0.f);
         }
     }
+#ifdef STN_ATTN_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    ATTN_STAMP(6);
+#endif
 }
 
 template <int DH, bool F16>
