@@ -40,6 +40,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950); "
                                 "the engine has no fallback path")
+    # PyTorch-ROCm wheels carry their own copy of the HIP runtime.  If libstn.so brings the system runtime in first, a later
+    # `import torch` in the same process finds no GPU ("No HIP GPUs are available"); the other order works (libstn.so then
+    # resolves against the runtime that is already loaded).  The multi-GPU helpers (supertonic_amd.dist) and bench.py need
+    # torch in the same process, so when torch is installed it is imported before the library (STN_NO_TORCH_PRELOAD=1 skips this).
+    import sys
+    if "torch" not in sys.modules and os.environ.get("STN_NO_TORCH_PRELOAD") != "1":
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cu64, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
     L.stn_version.restype = ctypes.c_char_p

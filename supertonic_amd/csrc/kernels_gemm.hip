@@ -976,13 +976,22 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int 
         pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
         pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.out) + o) = pk;
+    } else if (e.out_dtype == F16) {
+        uint2 pk;
+        pk.x = (unsigned)cvt16<true>(v[0]) | ((unsigned)cvt16<true>(v[1]) << 16);
+        pk.y = (unsigned)cvt16<true>(v[2]) | ((unsigned)cvt16<true>(v[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.out) + o) = pk;
     } else {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
 int gemm_splitk_factor(int dtype, int M, int N, int K, const Epilogue& e) {
-    // exact-fp32 GEMMs of one or two utterances: few 64x64 tiles, many K-steps of 32
+    // exact-fp32 GEMMs of one or two utterances: few 64x64 tiles, many K-steps of 32.
+    // NOT for the 16-bit modes, although a single utterance's 49 x 384 x 1536 pw2 would gain from it (10.3 -> ~7 us, measured:
+    // single-utterance latency 5.1 -> 4.96 ms): there the engine keeps a row's result independent of how many rows the launch
+    // has — a split changes the fp32 summation order with M, and a packed batch would stop being bit-identical to the padded one
+    // (tests/test_gpu_packed.py::test_trimmed_dense_vocoder_is_bit_identical).
     if (dtype != F32 || M > 128 || K < 1024 || K % 32 || N % 8 || e.ldo % 4 || e.mode > EPI_RESID) return 1;
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64), nk = K / 32;
     int sk = 1;
