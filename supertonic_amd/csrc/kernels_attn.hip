@@ -29,10 +29,64 @@ __device__ __forceinline__ void st_act(uint16_t* p, float v) {
 
 // stage `rows` rows (starting at sequence position pos0 of batch b) of one head into LDS, rotating pairs
 // (i, i + dh/2) when rope_mode >= 0; rows at positions >= limit are zero-filled.
+// fp32 rows: 16-byte loads, ALL of them issued before the first is consumed.  (Element by element this staging is a chain of
+// rows*dh/512 dependent 4-byte loads per tensor and key tile — 12 for a 64 x 96 tile — and was 3/4 of the kernel's 63 us on a
+// single utterance.)  Needs dh % 8 == 0, ld % 4 == 0 and 16-byte aligned rows; at most AK rows.
+__device__ __forceinline__ void stage_rows_f32v(const float* __restrict__ src, int ld, int64_t seq_base, int pos0, int rows,
+                                                int limit, int dh, int ds, float* __restrict__ dst, int rope_mode,
+                                                float log_base, float gamma, int seq_len, float mul) {
+    constexpr int MAXIT = (AK * (ADH_MAX / 8) + 255) / 256;  // 16-byte groups of half a row: rows * dh/8 of them, 256 threads
+    const int hd2 = dh >> 1, q4 = hd2 >> 2, items = rows * q4;
+    float4 a[MAXIT], b[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int idx = (int)threadIdx.x + it * 256;
+        const int r = idx / q4, c = idx - r * q4;
+        a[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b[it] = a[it];
+        if (idx < items && pos0 + r < limit) {
+            const float* p = src + (seq_base + pos0 + r) * ld + 4 * c;
+            a[it] = *reinterpret_cast<const float4*>(p);
+            b[it] = *reinterpret_cast<const float4*>(p + hd2);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int idx = (int)threadIdx.x + it * 256;
+        if (idx >= items) continue;
+        const int r = idx / q4, c = idx - r * q4;
+        const int pos = pos0 + r;
+        float x0[4] = {a[it].x, a[it].y, a[it].z, a[it].w}, x1[4] = {b[it].x, b[it].y, b[it].z, b[it].w};
+        if (rope_mode >= 0 && pos < limit) {
+            const float pp = rope_mode == 1 ? gamma * (float)pos / (float)(seq_len > 0 ? seq_len : 1) : (float)pos;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float inv = expf(-log_base * (float)(2 * (4 * c + e)) / (float)dh);
+                float sn, cs;
+                sincosf(pp * inv, &sn, &cs);
+                const float a0 = x0[e], a1 = x1[e];
+                x0[e] = a0 * cs - a1 * sn;
+                x1[e] = a1 * cs + a0 * sn;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[r * ds + 4 * c + e] = x0[e] * mul;
+            dst[r * ds + 4 * c + e + hd2] = x1[e] * mul;
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void stage_rows(const T* __restrict__ src, int ld, int64_t seq_base, int pos0, int rows,
                                            int limit, int dh, int ds, float* __restrict__ dst, int rope_mode,
                                            float log_base, float gamma, int seq_len, float mul) {
+    if constexpr (sizeof(T) == 4) {
+        if (dh % 8 == 0 && ld % 4 == 0 && rows <= AK && blockDim.x == 256 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            stage_rows_f32v(reinterpret_cast<const float*>(src), ld, seq_base, pos0, rows, limit, dh, ds, dst, rope_mode, log_base, gamma, seq_len, mul);
+            return;
+        }
+    }
     const int hd2 = dh >> 1;
     for (int idx = threadIdx.x; idx < rows * hd2; idx += blockDim.x) {
         const int r = idx / hd2, i = idx - r * hd2;
@@ -57,21 +111,28 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ src, int ld, in
     }
 }
 
-template <typename T>
+// TPR = threads per query row: 8 (32 query rows per workgroup, 8 keys of a 64-key tile and dh/8 output columns per thread) or 32
+// (8 query rows per workgroup, 2 keys and dh/32 columns per thread).  The work per thread — hence the latency of a launch that
+// cannot fill the chip anyway (a single utterance: 8 workgroups at TPR = 8) — shrinks 4x with TPR = 32, at the price of four times
+// as many workgroups staging the same keys; the launcher takes 32 when the grid would otherwise leave most CUs idle.
+template <typename T, int TPR>
 __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k,
                                                    const T* __restrict__ v, int ldk, T* __restrict__ o, int ldo, int Lq,
                                                    int Lk, int dh, const int* __restrict__ qlen,
                                                    const int* __restrict__ klen, int rope_mode, float log_base,
                                                    float gamma, int k_rot, const int* __restrict__ q_off,
                                                    const int* __restrict__ k_off) {
+    constexpr int QR = 256 / TPR;        // query rows per workgroup
+    constexpr int KPT = AK / TPR;        // keys per thread and tile
+    constexpr int OPT = (ADH_MAX + TPR - 1) / TPR;  // output columns per thread
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ds = dh + 1;
-    float* Qs = lds;               // [AQ][ds]
-    float* Ks = Qs + AQ * ds;      // [AK][ds]
+    float* Qs = lds;               // [QR][ds]
+    float* Ks = Qs + QR * ds;      // [AK][ds]
     float* Vs = Ks + AK * ds;      // [AK][ds]
-    float* Ss = Vs + AK * ds;      // [AQ][AK + 1]
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
-    const int tid = threadIdx.x, qi = tid >> 3, g = tid & 7;
+    float* Ss = Vs + AK * ds;      // [QR][AK + 1]
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QR;
+    const int tid = threadIdx.x, qi = tid / TPR, g = tid % TPR;
     const int nk = klen ? min(klen[b], Lk) : Lk;
     const int nq = qlen ? qlen[b] : Lq;  // used for length-aware positions only
     const float sc = rsqrtf((float)dh);
@@ -79,12 +140,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
     const int64_t qrow0 = q_off ? (int64_t)q_off[b] : (int64_t)b * Lq;  // packed: the sequence owns nq rows from q_off[b]
     const int qrows = q_off ? nq : Lq;
     if (q0 >= qrows) return;  // uniform: nothing of this tile exists
-    stage_rows<T>(q + h * dh, ldq, qrow0, q0, AQ, qrows, dh, ds, Qs, rope_mode, log_base, gamma, nq, sc);
+    stage_rows<T>(q + h * dh, ldq, qrow0, q0, QR, qrows, dh, ds, Qs, rope_mode, log_base, gamma, nq, sc);
 
     float m_run = -1e30f, l_run = 0.f;
-    float oacc[ADH_MAX / 8];
+    float oacc[OPT];
 #pragma unroll
-    for (int i = 0; i < ADH_MAX / 8; ++i) oacc[i] = 0.f;
+    for (int i = 0; i < OPT; ++i) oacc[i] = 0.f;
 
     for (int k0 = 0; k0 < nk; k0 += AK) {
         __syncthreads();  // previous tile fully consumed (and Qs visible on the first pass)
@@ -92,48 +153,46 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
         stage_rows<T>(k + h * dh, ldk, krow0, k0, AK, nk, dh, ds, Ks, k_rot ? -1 : rope_mode, log_base, gamma, nk, 1.f);
         stage_rows<T>(v + h * dh, ldk, krow0, k0, AK, nk, dh, ds, Vs, -1, 0.f, 0.f, 1, 1.f);
         __syncthreads();
-        float s[8];
+        float s[KPT];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) s[jj] = 0.f;
+        for (int jj = 0; jj < KPT; ++jj) s[jj] = 0.f;
         const float* qrow = Qs + qi * ds;
         for (int d = 0; d < dh; ++d) {
             const float qv = qrow[d];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) s[jj] = fmaf(qv, Ks[(g + 8 * jj) * ds + d], s[jj]);
+            for (int jj = 0; jj < KPT; ++jj) s[jj] = fmaf(qv, Ks[(g + TPR * jj) * ds + d], s[jj]);
         }
         float mx = -1e30f;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            if (k0 + g + 8 * jj >= nk) s[jj] = -1e30f;
+        for (int jj = 0; jj < KPT; ++jj) {
+            if (k0 + g + TPR * jj >= nk) s[jj] = -1e30f;
             mx = fmaxf(mx, s[jj]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+#pragma unroll
+        for (int sh = 1; sh < TPR; sh <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sh, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = expf(m_run - m_new);
         float ps = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < KPT; ++jj) {
             const float p = s[jj] <= -1e29f ? 0.f : expf(s[jj] - m_new);
             ps += p;
-            Ss[qi * (AK + 1) + g + 8 * jj] = p;
+            Ss[qi * (AK + 1) + g + TPR * jj] = p;
         }
-        ps += __shfl_xor(ps, 1, 64);
-        ps += __shfl_xor(ps, 2, 64);
-        ps += __shfl_xor(ps, 4, 64);
+#pragma unroll
+        for (int sh = 1; sh < TPR; sh <<= 1) ps += __shfl_xor(ps, sh, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < ADH_MAX / 8; ++i) oacc[i] *= alpha;
+        for (int i = 0; i < OPT; ++i) oacc[i] *= alpha;
         const float* prow = Ss + qi * (AK + 1);
         for (int j = 0; j < AK; ++j) {
             const float p = prow[j];
             const float* vrow = Vs + j * ds + g;
 #pragma unroll
-            for (int i = 0; i < ADH_MAX / 8; ++i)
-                if (8 * i < dh) oacc[i] = fmaf(p, vrow[8 * i], oacc[i]);
+            for (int i = 0; i < OPT; ++i)
+                if (TPR * i + g < dh) oacc[i] = fmaf(p, vrow[TPR * i], oacc[i]);
         }
     }
     const int gq = q0 + qi;
@@ -141,8 +200,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         T* orow = o + (qrow0 + gq) * ldo + h * dh + g;
 #pragma unroll
-        for (int i = 0; i < ADH_MAX / 8; ++i)
-            if (8 * i + g < dh) st_act(orow + 8 * i, oacc[i] * inv);
+        for (int i = 0; i < OPT; ++i)
+            if (TPR * i + g < dh) st_act(orow + TPR * i, oacc[i] * inv);
     }
 }
 
@@ -471,27 +530,29 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
         return;
     }
     const int ds = dh + 1;
-    const size_t lds = sizeof(float) * ((size_t)(AQ + 2 * AK) * ds + (size_t)AQ * (AK + 1));
-    const dim3 grid((Lq + AQ - 1) / AQ, H, B);
     const float log_base = logf(rope_base);
+    // few workgroups (single utterances): 32 threads per query row cut the work per thread, i.e. the launch's latency, by four
+    const bool wide = (int64_t)((Lq + AQ - 1) / AQ) * H * B < 96;
+    const int qr = wide ? 8 : AQ;
+    const size_t lds = sizeof(float) * ((size_t)(qr + 2 * AK) * ds + (size_t)qr * (AK + 1));
+    const dim3 grid((Lq + qr - 1) / qr, H, B);
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f32)");
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn bf16)");
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f16)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f32)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn bf16)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<f16_t, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f16)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f32 wide)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<uint16_t, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn bf16 wide)");
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<f16_t, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(attn f16 wide)");
     }
-    if (dtype == F16)
-        STN_KLAUNCH(attn_kernel<f16_t>, grid, dim3(256), lds, s, static_cast<const f16_t*>(q), ldq,
-                           static_cast<const f16_t*>(k), static_cast<const f16_t*>(v), ldk, static_cast<f16_t*>(o), ldo,
-                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
-    else if (dtype == BF16)
-        STN_KLAUNCH(attn_kernel<uint16_t>, grid, dim3(256), lds, s, static_cast<const uint16_t*>(q), ldq,
-                           static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), ldk, static_cast<uint16_t*>(o), ldo,
-                           Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
-    else
-        STN_KLAUNCH(attn_kernel<float>, grid, dim3(256), lds, s, static_cast<const float*>(q), ldq,
-                           static_cast<const float*>(k), static_cast<const float*>(v), ldk, static_cast<float*>(o), ldo, Lq, Lk,
-                           dh, qlen, klen, rope_mode, log_base, rope_gamma, (int)k_rotated, q_off, k_off);
+#define STN_ATTN_GO(T_, TPR_)                                                                                                  \
+    STN_KLAUNCH((attn_kernel<T_, TPR_>), grid, dim3(256), lds, s, static_cast<const T_*>(q), ldq, static_cast<const T_*>(k),      \
+                static_cast<const T_*>(v), ldk, static_cast<T_*>(o), ldo, Lq, Lk, dh, qlen, klen, rope_mode, log_base, rope_gamma, \
+                (int)k_rotated, q_off, k_off)
+    if (dtype == F16) { if (wide) STN_ATTN_GO(f16_t, 32); else STN_ATTN_GO(f16_t, 8); }
+    else if (dtype == BF16) { if (wide) STN_ATTN_GO(uint16_t, 32); else STN_ATTN_GO(uint16_t, 8); }
+    else { if (wide) STN_ATTN_GO(float, 32); else STN_ATTN_GO(float, 8); }
+#undef STN_ATTN_GO
 }
 
 // ---------------------------------------------------------------------------------------------

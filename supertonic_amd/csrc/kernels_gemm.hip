@@ -992,7 +992,9 @@ int gemm_splitk_factor(int dtype, int M, int N, int K, const Epilogue& e) {
     // single-utterance latency 5.1 -> 4.96 ms): there the engine keeps a row's result independent of how many rows the launch
     // has — a split changes the fp32 summation order with M, and a packed batch would stop being bit-identical to the padded one
     // (tests/test_gpu_packed.py::test_trimmed_dense_vocoder_is_bit_identical).
-    if (dtype != F32 || M > 128 || K < 1024 || K % 32 || N % 8 || e.ldo % 4 || e.mode > EPI_RESID) return 1;
+    // (fp32 itself: up to 512 rows and from K = 384 on — a single utterance's 49 x 1536 x 384 pw1 is 24 workgroups x 12 steps, its
+    // vocoder's 294 x 512 x 2048 pw2 40 workgroups x 64 steps; 20 -> 12 us and 99 -> 40 us)
+    if (dtype != F32 || M > 512 || K < 384 || K % 32 || N % 8 || e.ldo % 4 || e.mode > EPI_RESID) return 1;
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64), nk = K / 32;
     int sk = 1;
     for (int c : {8, 6, 4, 3, 2}) if (nk % c == 0 && nk / c >= 4 && tiles * c <= 256) { sk = c; break; }
