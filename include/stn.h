@@ -120,7 +120,7 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
 /* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
- * activation never leaves the registers (bf16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip
+ * activation never leaves the registers (bf16 and f16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip
  * idle while each still streams both weight matrices; other shapes keep the two GEMM launches).
  * Bit mask over the stages: 1 = vocoder, 2 = vector estimator, 4 = text encoder / duration predictor; 0 = never.  The default
  * is the set of stages where it measured faster on MI355X.  Same result as the two launches up to fp32

@@ -39,14 +39,24 @@ namespace stn {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-// the product kernel
+// the product kernel, bf16 operands ...
 #define STN_V_NODMA 0
 #define STN_V_NOGELU 0
 #define STN_V_EARLYRD 0
 #ifndef STN_V_ACCA
 #define STN_V_ACCA 0
 #endif
+#define STN_V_F16 0
 #include "kernels_ffn_body.inc"
+#undef STN_V_F16
+// ... and IEEE-half operands (the engine's f16 mode).  Same instruction stream; the GELU inside the blocks is the exp2 form in both
+// (|err| <= 5e-4 absolute: about one half-precision ulp at |y| ~ 1, where the two-launch f16 path uses the erf form).
+namespace f16k {
+#define STN_V_F16 1
+#include "kernels_ffn_body.inc"
+#undef STN_V_F16
+}
+#define STN_V_F16 0
 #undef STN_V_NODMA
 #undef STN_V_NOGELU
 #undef STN_V_EARLYRD
@@ -174,12 +184,11 @@ void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I
 }
 
 bool ffn_fused_supported(int dtype, int C, int I) {
-    // bf16 only: the GELU inside the asm blocks is the bf16 form of the pw1 epilogue (half keeps the erf form and stays unfused)
-    return dtype == BF16 && (C == 384 || C == 512) && I % 64 == 0 && I >= 128 && I <= 8192;
+    return is_half(dtype) && (C == 384 || C == 512) && I % 64 == 0 && I >= 128 && I <= 8192;
 }
 
 template <int C>
-static void launch_ffn_t(hipStream_t s, const FfnArgs& a) {
+static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
     const size_t lds = (size_t)4 * C * 64 + (size_t)(a.I + 2 * C) * 4;
     static PerDeviceOnce attr_once;
     if (attr_once.need())
@@ -198,6 +207,14 @@ static void launch_ffn_t(hipStream_t s, const FfnArgs& a) {
     if (var == 4) { go(&v_bare::ffn_fused_kernel<C>); return; }
     if (var == 5) { go(&v_nord::ffn_fused_kernel<C>); return; }
 #endif
+    if (dtype == F16) {
+        static PerDeviceOnce attr16;
+        if (attr16.need())
+            stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&f16k::ffn_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024), "hipFuncSetAttribute(ffn_fused f16)");
+        STN_KLAUNCH((f16k::ffn_fused_kernel<C>), grid, dim3(256), lds, s, a);
+        return;
+    }
     STN_KLAUNCH((ffn_fused_kernel<C>), grid, dim3(256), lds, s, a);
 }
 
@@ -207,8 +224,8 @@ void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a) {
     if ((size_t)a.M * a.ldx * 2 >= 0x7FFFFFFFull || a.ldx % 8 || a.ldo % 4 || (reinterpret_cast<uintptr_t>(a.xn) & 15) ||
         (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.rowvec && (a.rv_ld % 4 || (reinterpret_cast<uintptr_t>(a.rowvec) & 15))))
         throw std::invalid_argument("launch_ffn_fused: operand alignment / size violates the kernel contract");
-    if (C == 384) launch_ffn_t<384>(s, a);
-    else launch_ffn_t<512>(s, a);
+    if (C == 384) launch_ffn_t<384>(s, dtype, a);
+    else launch_ffn_t<512>(s, dtype, a);
 }
 
 }  // namespace stn

@@ -122,7 +122,7 @@ def test_c4_full_size_sharding_invariance(eng_bf16):
         assert mx < 2e-2, (i, mx)  # different tile shapes / summation orders in bf16, same math
 
 
-def test_c3_full_size_bench_workload_matches_oracle(ref, eng_f32, eng_bf16):
+def test_c3_full_size_bench_workload_matches_oracle(ref, eng_f32, eng_bf16, eng_f16):
     """BASELINE.json configs[2] — exactly what bench.py times: 128 ten-word utterances, 5 Euler steps, the 66 M stack, forced
     durations, utterance-keyed Philox noise.  The fp32 CPU oracle does this batch in ~15 s on the box's cores, so the full
     size is checked directly rather than through properties: fp32 engine and bf16 engine against the oracle, then
@@ -146,6 +146,9 @@ def test_c3_full_size_bench_workload_matches_oracle(ref, eng_f32, eng_bf16):
     w16, d16 = eng_bf16.synthesize(tid, mask, sttl, sdp, 5, 1.05, duration_override=durs, noise_seed=1234, utt_ids=ids_all)
     assert w16.shape == rw.shape == (128, 78 * 3072)
     parity_check("c3.full_size_wav", "bf16", w16, rw, "e2e")
+    # IEEE-half mode on the same batch (its vocoder runs the f16 instantiation of K4 at this size)
+    wh, _ = eng_f16.synthesize(tid, mask, sttl, sdp, 5, 1.05, duration_override=durs, noise_seed=1234, utt_ids=ids_all)
+    parity_check("c3.full_size_wav", "f16", wh, rw, "e2e")
     # per-utterance: no single utterance is an outlier hidden by the batch rms
     worst = max(range(128), key=lambda i: rel_err(w16[i], rw[i])[1])
     parity_check("c3.full_size_worst_utterance_wav", "bf16", w16[worst], rw[worst], "e2e")

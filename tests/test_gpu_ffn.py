@@ -106,3 +106,41 @@ def test_ffn_identity_weights_catch_layout_errors(eng):
     got = eng.op_ffn(xn, W1, b1, W2, None, None, np.zeros((M, C), np.float32), fused=True)
     ref = bf16_round(gelu(xn.astype(np.float64)).astype(np.float32))[:, P[:C]]
     assert np.max(np.abs(got - ref)) < 8e-3  # bf16 GELU form vs erf, then one bf16 rounding
+
+
+# ---- the IEEE-half instantiation (f16 engines): same kernel text, v_mfma_f32_32x32x16_f16 / v_cvt_pk_f16_f32 ----------------
+
+@pytest.fixture(scope="module")
+def eng16():
+    e = binding.Engine(0, "f16")
+    e.load_synthetic(tiny_arch(), 7)
+    return e
+
+
+def f16_round(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,C,I,nseq", [(300, 512, 2048, 0), (7436, 384, 1536, 128), (4096, 512, 2048, 0)])
+def test_ffn_fused_f16_vs_float64_and_two_launches(eng16, M, C, I, nseq):
+    ops = make(M, C, I, M + C + I + 1, nseq)
+    xn, W1, b1, W2, b2, gamma, x, rowvec, row_b = ops
+    got = eng16.op_ffn(*ops[:7], rowvec=rowvec, row_b=row_b, fused=True)
+    h = f16_round(xn).astype(np.float64) @ f16_round(W1).astype(np.float64).T + b1
+    y = f16_round(gelu(h).astype(np.float32)).astype(np.float64) @ f16_round(W2).astype(np.float64).T + b2
+    ref = x + gamma * y + (rowvec[row_b] if rowvec is not None else 0.0)
+    mx, rms = rel_err(got - x, ref - x)
+    # the exp2-form GELU inside the blocks (|err| <= 5e-4 absolute) is what is left once the operands carry 11 bits
+    assert rms < 1.5e-3 and mx < 1.5e-2 and np.all(np.isfinite(got)), (mx, rms)
+    two = eng16.op_ffn(*ops[:7], rowvec=rowvec, row_b=row_b, fused=False)  # erf-form GELU, two launches
+    mx2, rms2 = rel_err(got - x, two - x)
+    assert rms2 < 1.5e-3 and mx2 < 1.5e-2, (mx2, rms2)
+
+
+def test_ffn_f16_rows_do_not_depend_on_position(eng16):
+    M, C, I = 700, 512, 2048
+    ops = make(M, C, I, 6)
+    full = eng16.op_ffn(*ops[:7], fused=True)
+    sel = np.r_[3:40, 129:300, 511:700]
+    part = eng16.op_ffn(ops[0][sel], *ops[1:6], ops[6][sel], fused=True)
+    assert np.array_equal(full[sel], part)
