@@ -353,7 +353,9 @@ static bool launch_dwconv_ln_v3(hipStream_t s, const float* x, int nseq, int L, 
         else if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
         else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     } else if (row_off) {  // the packed layout only exists in this kernel
-        if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+        // (a single utterance: ~15 wavefronts at combs of 4 — combs of 2 halve the serial work per wavefront)
+        if (k == 5 && M < 1024) launch_dwconv_ln_v3_kr<OutT, 5, 2>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+        else if (k == 5) launch_dwconv_ln_v3_kr<OutT, 5, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
         else launch_dwconv_ln_v3_kr<OutT, 7, 4>(s, x, nseq, L, C, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     } else {
         return false;  // few frames: one wave per 2 frames (v2) exposes more parallelism
