@@ -128,6 +128,8 @@ void Engine::drop_graphs() {
     for (auto& g : graphs_) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
+        if (g.exec2) (void)hipGraphExecDestroy(g.exec2);
+        if (g.graph2) (void)hipGraphDestroy(g.graph2);
     }
     graphs_.clear();
     warm_keys_.clear();
@@ -695,7 +697,8 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
 
 // K/V of the text and style contexts for every main block: invariant across Euler steps.
 // The returned buffers live in the arena ABOVE the caller's mark: the caller releases them.
-Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen, const Ragged* trg) {
+Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen, const Ragged* trg,
+                                     bool defer_text) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, nb = a.ve_main_blocks;
@@ -705,16 +708,25 @@ Engine::VeCtx Engine::ve_prepare_dev(int B, int Lt, const void* text_rows, const
     c.text_off = trg ? trg->off : nullptr;
     c.text_kv = act_alloc(Mt * nb * 2 * C);
     c.style_kv = act_alloc((int64_t)B * a.n_style_ttl * nb * 2 * C);
-    Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = c.text_kv; e.ldo = nb * 2 * C;
-    gemm("gemm_kv", dt_, text_rows, a.te_out_dim, linear("ve.text_kv_all"), (int)Mt, e);
-    // LARoPE of the text keys does not depend on the Euler step or on the query: rotate all blocks' keys once
-    // (was re-done by every one of the main_blocks x total_step attention launches)
-    launch_rope_rows(s_, dt_, c.text_kv, nb * 2 * C, B, Lt, tlen, nb, 2 * C, a.ve_heads, C / a.ve_heads, 1, a.rope_base, a.larope_gamma,
-                     c.text_off);
+    if (!defer_text) ve_text_kv_dev(c, B, Lt, text_rows, tlen, trg);
     void* st = to_act(style_ttl, (int64_t)B * a.n_style_ttl * a.d_style_ttl);
     Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = dt_; e2.out = c.style_kv; e2.ldo = nb * 2 * C;
     gemm("gemm_kv", dt_, st, a.d_style_ttl, linear("ve.style_kv_all"), B * a.n_style_ttl, e2);
     return c;
+}
+// K and V of the text context for all main blocks in one GEMM, keys rotated once (they depend neither on the Euler step nor on the query)
+void Engine::ve_text_kv_dev(const VeCtx& c, int B, int Lt, const void* text_rows, const int* tlen, const Ragged* trg) {
+    const char* saved = stage_;
+    stage_ = "ve";
+    const stn_arch& a = a_;
+    const int C = a.ve_dim, nb = a.ve_main_blocks;
+    const int64_t Mt = trg ? (int64_t)trg->rows : (int64_t)B * Lt;
+    Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = c.text_kv; e.ldo = nb * 2 * C;
+    gemm("gemm_kv", dt_, text_rows, a.te_out_dim, linear("ve.text_kv_all"), (int)Mt, e);
+    // LARoPE of the text keys: rotate all blocks' keys once (was re-done by every one of the main_blocks x total_step attention launches)
+    launch_rope_rows(s_, dt_, c.text_kv, nb * 2 * C, B, Lt, tlen, nb, 2 * C, a.ve_heads, C / a.ve_heads, 1, a.rope_base, a.larope_gamma,
+                     c.text_off);
+    stage_ = saved;
 }
 
 // sinusoid(t * scale) -> Linear -> SiLU -> Linear -> per-block Linear, for `rows` independent (current, total) pairs
@@ -771,6 +783,9 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         const char* kp = static_cast<const char*>(kv_all) + (size_t)blk * 2 * C * esz;
         const char* vp = kp + (size_t)C * esz;
         void* o = act_alloc(M * C);
+        // the first text cross-attention of a resident-batch run is where the text encoder's rows are needed: take them (and
+        // compute the text K/V) here, not at the head of the pipeline, so that everything before runs beside the encoder
+        if (kv_all == c.text_kv && text_gate_) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }
         if (prof_on_) prof_begin("attention", 4.0 * M * (double)Lk * C, (double)(M * 2 + (int64_t)B * Lk * 2) * C * esz);
         launch_attention(s_, dt_, qb, C, kp, vp, nb * 2 * C, o, C, B, L, Lk, H, C / H, llen, klen, rope_mode, a.rope_base,
                          a.larope_gamma, /*k_rotated=*/rope_mode >= 0, roff, kv_all == c.text_kv ? c.text_off : nullptr);
@@ -1175,11 +1190,16 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
         if (b.have_override) dur = b.h_dur;  // known on the host: no device->host read, no sync
         else STN_HIP(hipEventSynchronize(ev_dp_));  // the one host round trip (the predictor only): L = f(max duration) sizes every later buffer
     }
-    // head of the main pipeline: take this run's text rows (everything captured below reads b.text_rows)
-    if (te_s_) STN_HIP(hipStreamWaitEvent(s_, ev_te_, 0));
-    STN_HIP(hipMemcpyAsync(b.text_rows, b.text_side, text_bytes, hipMemcpyDeviceToDevice, s_));
-    STN_HIP(hipEventRecord(ev_copied_, s_));
-    copied_valid_ = true;
+    // Hand-over of this run's text rows to the main pipeline (everything captured below reads b.text_rows).  It happens where the
+    // rows are first needed — in front of the text K/V GEMM of the first text cross-attention — so the noise, the style K/V, the time
+    // conditioning and the first ConvNeXt blocks of the estimator run beside the encoder; a captured pipeline is therefore TWO
+    // graphs with this hand-over between them.
+    auto take_text_rows = [this, &b, text_bytes]() {
+        if (te_s_) STN_HIP(hipStreamWaitEvent(s_, ev_te_, 0));
+        STN_HIP(hipMemcpyAsync(b.text_rows, b.text_side, text_bytes, hipMemcpyDeviceToDevice, s_));
+        STN_HIP(hipEventRecord(ev_copied_, s_));
+        copied_valid_ = true;
+    };
     for (float& d : dur) d /= speed;  // cpp/helper.cpp:529-531
     int L = 0;
     latent_geometry(a, dur, L, b.h_llen);
@@ -1235,6 +1255,8 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
             if (g.key == key) {
                 g.last_use = ++graph_clock_;
                 STN_HIP(hipGraphLaunch(g.exec, s_));
+                take_text_rows();
+                STN_HIP(hipGraphLaunch(g.exec2, s_));
                 ++graph_replays_;
                 return;
             }
@@ -1246,27 +1268,44 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
         STN_HIP(hipStreamBeginCapture(s_, hipStreamCaptureModeThreadLocal));
         bool ok = true;
         std::string why;
-        try { enqueue_after_duration(total_step); } catch (const std::exception& e) { ok = false; why = e.what(); }
-        hipGraph_t g = nullptr;
-        const hipError_t ec = hipStreamEndCapture(s_, &g);
+        hipGraph_t g = nullptr, g2 = nullptr;
+        hipError_t ec1 = hipErrorUnknown;
+        bool split = false;
+        // at the hand-over the first graph ends and the second begins (the hand-over itself is issued between their launches)
+        auto split_capture = [&]() {
+            ec1 = hipStreamEndCapture(s_, &g);
+            split = true;
+            STN_HIP(hipStreamBeginCapture(s_, hipStreamCaptureModeThreadLocal));
+        };
+        try { enqueue_after_duration(total_step, split_capture); } catch (const std::exception& e) { ok = false; why = e.what(); }
+        const hipError_t ec = hipStreamEndCapture(s_, &g2);
+        text_gate_ = nullptr;
         ar_.release(cap0);
-        hipGraphExec_t ex = nullptr;
-        if (ok && ec == hipSuccess && g && ar_.capacity() == cap_before && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+        hipGraphExec_t ex = nullptr, ex2 = nullptr;
+        if (ok && split && ec1 == hipSuccess && ec == hipSuccess && g && g2 && ar_.capacity() == cap_before &&
+            hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && hipGraphInstantiate(&ex2, g2, nullptr, nullptr, 0) == hipSuccess) {
             if (graphs_.size() >= kGraphCache) {  // evict the least recently used entry
                 auto lru = std::min_element(graphs_.begin(), graphs_.end(), [](const GraphEntry& x, const GraphEntry& y) { return x.last_use < y.last_use; });
                 sync();  // its last replay may still be running
                 (void)hipGraphExecDestroy(lru->exec);
                 (void)hipGraphDestroy(lru->graph);
+                if (lru->exec2) (void)hipGraphExecDestroy(lru->exec2);
+                if (lru->graph2) (void)hipGraphDestroy(lru->graph2);
                 graphs_.erase(lru);
             }
             GraphEntry e;
-            e.key = key; e.graph = g; e.exec = ex; e.last_use = ++graph_clock_;
+            e.key = key; e.graph = g; e.exec = ex; e.graph2 = g2; e.exec2 = ex2; e.last_use = ++graph_clock_;
             graphs_.push_back(e);
             warm_keys_.erase(warm);
             STN_HIP(hipGraphLaunch(ex, s_));
+            take_text_rows();
+            STN_HIP(hipGraphLaunch(ex2, s_));
             ++graph_replays_;
             return;
         }
+        if (ex) (void)hipGraphExecDestroy(ex);
+        if (ex2) (void)hipGraphExecDestroy(ex2);
+        if (g2) (void)hipGraphDestroy(g2);
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
         if (!ok) throw std::runtime_error("graph capture failed: " + why);
@@ -1276,11 +1315,11 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
         if (warm_keys_.size() >= kWarmKeys) warm_keys_.erase(warm_keys_.begin());
         warm_keys_.push_back(key);
     }
-    enqueue_after_duration(total_step);
+    enqueue_after_duration(total_step, take_text_rows);
 }
 
 // Everything after the duration read: lengths to the device, text encoder, initial latent, Euler loop, vocoder.
-void Engine::enqueue_after_duration(int total_step) {
+void Engine::enqueue_after_duration(int total_step, const std::function<void()>& take_text_rows) {
     Batch& b = bt_;
     const stn_arch& a = a_;
     const int B = b.B, Lt = b.Lt, L = b.L, D = a.latent_dim * a.chunk_compress_factor;
@@ -1301,7 +1340,14 @@ void Engine::enqueue_after_duration(int total_step) {
         launch_randn_masked(s_, 0, b.utt_ids, B, D, L, b.llen, b.xt[0], seed_dev_);
     }
     // 4. Euler loop: step-invariant K/V once, the time conditioning of every step in one pass, then total_step passes
-    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen, trgp);
+    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen, trgp, /*defer_text=*/true);
+    // armed here, fired by the first text cross-attention of the first Euler step (ve_step_dev): hand-over of the rows, then the text K/V
+    text_gate_ = [this, &c, &b, &take_text_rows, B, Lt, text_rows, trgp]() {
+        take_text_rows();
+        ve_text_kv_dev(c, B, Lt, text_rows, b.tlen, trgp);
+    };
+    struct Disarm { std::function<void()>& g; ~Disarm() { g = nullptr; } } disarm{text_gate_};  // it refers to this frame: never outlives it
+    if (a.ve_main_blocks == 0) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }  // (no cross-attention would ever fire it)
     float* tot_all = f32_alloc((int64_t)total_step * B);
     float* cur_all = f32_alloc((int64_t)total_step * B);
     float* dt_all = f32_alloc(B);

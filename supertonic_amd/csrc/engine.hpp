@@ -95,7 +95,9 @@ class Engine {
                       const Ragged* trg = nullptr);
     struct VeCtx { void* text_kv = nullptr; void* style_kv = nullptr; int Lt = 0; const int* text_off = nullptr; };  // step-invariant K/V
     // tlen: text lengths (the text keys are rotated here, once, with their length-aware positions)
-    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen, const Ragged* trg = nullptr);
+    // defer_text: allocate the text K/V but leave them to ve_text_kv_dev (batch_run computes them behind the text-row hand-over)
+    VeCtx ve_prepare_dev(int B, int Lt, const void* text_rows, const float* style_ttl, const int* tlen, const Ragged* trg = nullptr, bool defer_text = false);
+    void ve_text_kv_dev(const VeCtx& c, int B, int Lt, const void* text_rows, const int* tlen, const Ragged* trg);
     // time conditioning of `rows` (= B x steps) (current, total) pairs -> tb [rows][main_blocks * C] (fp32, arena)
     float* ve_time_cond_dev(int rows, const float* total_step, const float* current_step);
     // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
@@ -276,7 +278,7 @@ class Engine {
     std::vector<void*> batch_retired_;  // outgrown buffers: freed at the next upload, after the stream has drained
     template <typename T> void ensure(T*& p, size_t& cap, size_t need);
     std::vector<float> reported_dur_;
-    void enqueue_after_duration(int total_step);
+    void enqueue_after_duration(int total_step, const std::function<void()>& take_text_rows);
     // A captured graph holds raw pointers: everything it can have baked in is part of its key — the batch buffers (`gen`, bumped
     // by every reallocation), the weights (`wgen`, bumped by every load), the pinned staging the copy nodes read, the stream.
     struct GraphKey {
@@ -290,7 +292,8 @@ class Engine {
     // LRU cache of captured graphs (the reference's call() loop and the n_test loop alternate a few shapes,
     // /root/reference/cpp/helper.cpp:697-719, cpp/example_onnx.cpp:88): a shape is captured the second time it is seen
     // (`warm_keys_`: the arena must have seen its allocation sequence once) and replayed from then on.
-    struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
+    // (graph / exec: the pipeline up to the first text cross-attention; graph2 / exec2: the rest — the text encoder's rows are taken between the two)
+    struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr, graph2 = nullptr; hipGraphExec_t exec = nullptr, exec2 = nullptr; uint64_t last_use = 0; };
     static constexpr size_t kGraphCache = 8, kWarmKeys = 16;
     std::vector<GraphEntry> graphs_;
     std::vector<GraphKey> warm_keys_;
@@ -309,6 +312,7 @@ class Engine {
     // text_side; the main stream waits for ev_te_, copies the rows into text_rows (what the graphs read) and records ev_copied_,
     // which the side stream waits for before the NEXT run's encoder overwrites text_side (prefetch depth: one run).
     hipEvent_t ev_te_ = nullptr, ev_copied_ = nullptr, ev_dp_ = nullptr;
+    std::function<void()> text_gate_;  // armed by enqueue_after_duration, fired once by the first text cross-attention of the run
     bool copied_valid_ = false;
     int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
