@@ -142,7 +142,10 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
         if (man.has("arch")) {
             for (const auto& kv : man.at("arch").obj) {
                 if (kv.first == "vo_dilations") {
-                    for (size_t i = 0; i < kv.second.arr.size() && i < STN_MAX_VO_BLOCKS; ++i) a.vo_dilations[i] = kv.second.arr[i].as_int();
+                    if (kv.second.arr.size() > STN_MAX_VO_BLOCKS)
+                        throw std::runtime_error("manifest: vo_dilations has " + std::to_string(kv.second.arr.size()) + " entries, at most " +
+                                                 std::to_string(STN_MAX_VO_BLOCKS) + " vocoder blocks are supported");
+                    for (size_t i = 0; i < kv.second.arr.size(); ++i) a.vo_dilations[i] = kv.second.arr[i].as_int();
                     continue;
                 }
                 auto it = arch_fields().find(kv.first);

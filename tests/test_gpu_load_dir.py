@@ -111,6 +111,11 @@ def test_load_dir_error_paths(tmp_path):
     (tmp_path / "stn_weight_map.json").write_text(json.dumps(broken))
     with pytest.raises(binding.StnError, match='no entry for tensor "vo.head.w"'):
         eng.load_dir(str(tmp_path))
+    toolong = dict(man)
+    toolong["arch"] = dict(man["arch"], vo_dilations=[1] * (len(man["arch"]["vo_dilations"]) + 1))
+    (tmp_path / "stn_weight_map.json").write_text(json.dumps(toolong))
+    with pytest.raises(binding.StnError, match="vo_dilations has .* entries, at most"):
+        eng.load_dir(str(tmp_path))
     broken["tensors"]["vo.head.w"] = {"file": "vocoder.onnx", "name": "/model/vo/head/b"}
     (tmp_path / "stn_weight_map.json").write_text(json.dumps(broken))
     with pytest.raises(binding.StnError, match="elements, descriptor wants"):
