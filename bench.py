@@ -42,11 +42,86 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch utterances per GPU; strong: --batch utterances in all")
     ap.add_argument("--no-host-loop", action="store_true", help="skip the host-to-host loop (value_host)")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-utterance record (config C2)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0: pick a free one)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here — one process per GPU through
+    torch.distributed.run — BEFORE anything in this process touches a GPU, pass rank 0's JSON line through (the children inherit
+    stdout) and return their exit code.  Fewer than N visible GPUs is an error, never a silent one-rank run."""
+    import socket
+    import subprocess
+    stub = os.environ.get("STN_BENCH_STUB") == "1"
+    if not stub:
+        import torch
+        have = torch.cuda.device_count()  # (counts devices without initialising the runtime)
+        if have < args.gpus:
+            print(f"[bench] error: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to run a smaller job under that label",
+                  file=sys.stderr)
+            return 2
+    port = args.master_port
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(args):
+    """STN_BENCH_STUB=1: the launch / rendezvous / max-over-ranks / one-JSON-line skeleton with a stand-in step and the gloo backend —
+    what the CPU test of the spawn path runs (tests/test_bench_spawn_cpu.py).  Nothing here is a measurement."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from supertonic_amd.dist import bench_shards
+    texts_all, shards = bench_shards(args.batch, world, args.scaling, args.mixed, args.words)
+    mine = shards[rank]
+    audio = float(sum(len(texts_all[i]) for i in mine)) / 15.0 / args.speed
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    fence()
+    el = torch.tensor([time.perf_counter() - t0, audio], dtype=torch.float64)
+    if world > 1:
+        mx = el.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(el, op=dist.ReduceOp.SUM)
+        el[0] = mx[0]
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(float(el[1]) * args.steps / float(el[0]), 1), "unit": "audio-sec/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(el[0]) / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub", "batch_per_gpu": len(mine), "global_batch": len(texts_all)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if os.environ.get("STN_BENCH_STUB") == "1":
+        sys.exit(stub_main(args))
     # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner at communicator
     # creation, for one) is diverted to stderr for the whole run
     sys.stdout.flush()
@@ -61,28 +136,37 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] error: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
+    if torch.cuda.device_count() <= local:
+        print(f"[bench] error: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible", file=sys.stderr)
+        sys.exit(2)
     # the multi-GPU code path (process group, shared stream, waveform gather); STN_BENCH_FORCE_DIST=1 exercises it at world 1
     use_dist = world > 1 or os.environ.get("STN_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     # ---- workload: 128*N utterances, sorted by length and dealt round-robin ---------------------
     arch = default_arch()
     from supertonic_amd.dist import bench_shards
-    texts_all, shards = bench_shards(args.batch, world, args.scaling, args.mixed, args.words)
-    n_total = len(texts_all)
-    mine = shards[rank]
-    texts = [texts_all[i] for i in mine]
     up = host.UnicodeProcessor(host.synthetic_indexer())
-    ids, mask = up(texts, ["en"] * len(texts))
-    sttl, sdp = workload.synthetic_styles(arch, mine)
-    durs = workload.forced_durations(texts)
+
+    def make_shard(scaling):
+        texts_all_, shards_ = bench_shards(args.batch, world, scaling, args.mixed, args.words)
+        mine_ = shards_[rank]
+        texts_ = [texts_all_[i] for i in mine_]
+        ids_, mask_ = up(texts_, ["en"] * len(texts_))
+        sttl_, sdp_ = workload.synthetic_styles(arch, mine_)
+        return dict(n_total=len(texts_all_), mine=mine_, texts=texts_, ids=ids_, mask=mask_, sttl=sttl_, sdp=sdp_, durs=workload.forced_durations(texts_))
+
+    sh = make_shard(args.scaling)
+    n_total, mine, texts, ids, mask, sttl, sdp, durs = (sh[k] for k in ("n_total", "mine", "texts", "ids", "mask", "sttl", "sdp", "durs"))
 
     eng = binding.Engine(local, args.dtype)
     eng.load_synthetic(arch, 7)
@@ -97,6 +181,7 @@ def main():
 
     gather_buf = {}
     step_no = [0]
+    cur = {"durs": durs}
 
     def step():
         if use_dist and "plan" in gather_buf:
@@ -104,8 +189,8 @@ def main():
         eng.batch_run(args.total_step, args.speed, 1234)
         if use_dist:
             B, L, W = eng.batch_dims()
-            if gather_buf.get("shape") != (B, W):  # first step only: buffers + the one-time shape exchange
-                gather_buf["dur"] = torch.tensor(durs / args.speed, dtype=torch.float32, device=dev)
+            if gather_buf.get("shape") != (B, W):  # first step of a shape only: buffers + the one-time shape exchange
+                gather_buf["dur"] = torch.tensor(cur["durs"] / args.speed, dtype=torch.float32, device=dev)
                 gather_buf["plan"] = GatherPlan((B, W), dev, torch.int16, dst=0, slots=2)
                 gather_buf["shape"] = (B, W)
             plan, k = gather_buf["plan"], step_no[0] & 1
@@ -125,11 +210,70 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
-    # ---- warm-up (also sizes the workspace) + one fully profiled step to find the dominant kernel family ------
-    for _ in range(max(1, args.warmup)):
+    def timed(k_steps):
+        """K steps between barrier + synchronize on both sides; the MAX over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k_steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def audio_total(durs_rank):
+        a_ = float((durs_rank / np.float32(args.speed)).sum())
+        if use_dist:
+            t = torch.tensor([a_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            a_ = float(t.item())
+        return a_
+
+    # ---- warm-up (sizes the workspace; the shape is captured as a hipGraph the second time it is seen and replayed from the third
+    # step on: at least three untimed steps, so that the timed region below is what a host's n_test loop runs — graph replays,
+    # /root/reference/cpp/example_onnx.cpp:88-97)
+    n_warm = max(3, args.warmup)
+    for _ in range(n_warm):
         step()
-    fence()
-    dominant, fam_stats = None, {}
+    replays0 = eng.graph_replays
+
+    # ---- timed region: exactly K steps (hipGraph replays of the post-duration pipeline) between barrier + synchronize -----------
+    elapsed = timed(args.steps)
+    replays_timed = eng.graph_replays - replays0
+
+    # ---- p50 per-utterance latency: completion time of the batch that contains the utterance ---------------------
+    lat = []
+    for _ in range(min(5, max(2, args.steps))):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    p50 = float(np.median(lat))
+
+    # ---- the gathered waveforms against the engine's own PCM fetch (N > 1 code path): rank 0's block of the last gather must be the
+    # bytes stn_batch_fetch_pcm16 returns for the same resident batch, and every rank's block must have arrived with its shape ---------
+    gather_check = None
+    if use_dist:
+        import zlib
+        fence()
+        k_last = (step_no[0] - 1) & 1
+        wavs, durs_g = gather_buf["plan"].result(k_last)
+        if rank == 0:
+            pcm_ref, dur_ref = eng.batch_fetch_pcm16()
+            got = wavs[0].cpu().numpy()
+            gather_check = {"equal_rank0_block": bool(np.array_equal(got, pcm_ref)), "crc32_gathered": zlib.crc32(got.tobytes()),
+                            "crc32_fetch_pcm16": zlib.crc32(pcm_ref.tobytes()), "durations_equal": bool(np.allclose(durs_g[0].cpu().numpy(), dur_ref, rtol=0, atol=1e-6)),
+                            "blocks": [list(w.shape) for w in wavs], "nonzero_blocks": [bool(int(w.abs().max()) > 0) for w in wavs], "bytes_per_gather": int(sum(w.numel() for w in wavs) * 2)}
+
+    # ---- kernel timing, separate from the timed region: events ride on dispatch packets and cannot live inside a graph, so these
+    # passes run eager.  One fully instrumented step finds the dominant family; then the same K steps with events on every 7th
+    # launch of that family give its live average duration (roofline.achieved) -------------------------------------------------
+    dominant, fam_stats, roof, eager = None, {}, None, None
+    sample_every = 1
     if not args.no_profile:
         eng.profile_filter(None)
         eng.profile_enable(True)
@@ -139,30 +283,18 @@ def main():
         fam_stats = eng.profile()
         eng.profile_enable(False)
         dominant = max(fam_stats, key=lambda k: fam_stats[k]["ms"])
-        eng.profile_filter(dominant)  # the timed region carries events around this family only ...
-        # ... and around every 7th launch of it: an event-carrying launch does not overlap its neighbours (~4 us each, 0.5 ms
-        # per step when all 140 launches of an estimator family carry them); 7 is coprime to the launches per step, so the
-        # sample walks through every layer position
+        eng.profile_filter(dominant)
+        # an event-carrying launch does not overlap its neighbours (~4 us each); 7 is coprime to the launches per step, so the sample
+        # walks through every layer position
         sample_every = 7 if fam_stats[dominant]["launches"] >= 28 else 1
         eng.profile_sample(sample_every)
         eng.profile_reset()
         eng.profile_enable(True)
-
-    # ---- timed region: exactly K steps between barrier + synchronize ------------------------------------------
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    roof = None
-    if dominant:
+        el_e = timed(args.steps)
         st = eng.profile()[dominant]
         eng.profile_enable(False)
+        eager = {"ms_per_step": round(el_e / args.steps * 1e3, 3),
+                 "note": "the same K steps launched eagerly with HIP events on every %d-th launch of the dominant family (the pass roofline.avg_launch_us comes from)" % sample_every}
         avg_ms = st["ms"] / max(st["launches"], 1)
         flops_per_launch = st["flops"] / max(st["launches"], 1)
         bytes_per_launch = st["bytes"] / max(st["launches"], 1)
@@ -193,53 +325,46 @@ def main():
             if "rocprof_avg_us" in pmc:
                 roof["rocprof_avg_us"] = round(pmc["rocprof_avg_us"], 2)
                 roof["timing_note"] = ("avg_launch_us: HIP events attached to each launch's dispatch packet on the engine's stream "
-                                       "(hipExtLaunchKernelGGL start/stop = the kernel's own begin/end), live over the timed region, where "
+                                       "(hipExtLaunchKernelGGL start/stop = the kernel's own begin/end), live over K eagerly launched steps, where "
                                        "its un-instrumented neighbours may overlap its first and last microsecond (a fully instrumented "
                                        "step, `roofline_other`, serialises every launch and reads ~8 % lower); "
                                        "rocprof_avg_us: the same kernel in the committed rocprofv3 kernel trace")
-
-    # ---- the same K steps as hipGraph replays (no event timing possible inside a graph): informational, not `value` --------
-    graph = None
-    if not args.no_profile:
-        eng.profile_enable(False)
-        for _ in range(3):  # eager warm-up of the shape, capture, first replay
-            step()
-        fence()
-        tg = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        tg = time.perf_counter() - tg
-        graph = {"ms_per_step": round(tg / args.steps * 1e3, 3), "replays": eng.graph_replays}
-
-    # ---- p50 per-utterance latency: completion time of the batch that contains the utterance ---------------------
-    lat = []
-    for _ in range(min(5, max(2, args.steps))):
-        fence()
-        t1 = time.perf_counter()
-        step()
-        fence()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    p50 = float(np.median(lat))
 
     # ---- host-to-host: text frontend -> pinned upload -> synthesis -> 16-bit PCM in host memory, per batch --------------------
     hostrec = None
     if not args.no_host_loop:
         hostrec = host_loop(eng, up, texts, sttl, sdp, durs, mine, args, fence)
 
-    audio_per_step_rank = float((durs / np.float32(args.speed)).sum())
-    if use_dist:
-        t = torch.tensor([audio_per_step_rank], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        audio_per_step = float(t.item())
-    else:
-        audio_per_step = audio_per_step_rank
+    audio_per_step = audio_total(durs)
     value = audio_per_step * args.steps / elapsed
 
     if hostrec and use_dist:  # every rank takes part in the max over ranks
         t = torch.tensor([hostrec["elapsed"]], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         hostrec["elapsed"] = float(t.item())
+
+    # ---- the other scaling mode, in the same run (N > 1): north_star words the job as "a 128-utterance batch at 1, 2, 4 and 8
+    # MI355X" (strong: 128 in all), the driver's efficiency curve wants fixed work per GPU (weak: 128 each).  `value` is --scaling's;
+    # the other figure is reported beside it ------------------------------------------------------------------------------------
+    other_scaling = None
+    if world > 1:
+        om = "strong" if args.scaling == "weak" else "weak"
+        so = make_shard(om)
+        fence()
+        eng.batch_upload(so["ids"], so["mask"], so["sttl"], so["sdp"], duration_override=so["durs"], utt_ids=so["mine"])
+        cur["durs"] = so["durs"]
+        gather_buf.clear()
+        for _ in range(3):
+            step()
+        el_o = timed(args.steps)
+        a_o = audio_total(so["durs"])
+        other_scaling = {"scaling": om, "value": round(a_o * args.steps / el_o, 1), "ms_per_step": round(el_o / args.steps * 1e3, 3),
+                         "global_batch": so["n_total"], "batch_per_gpu": len(so["texts"]), "audio_sec_per_step": round(a_o, 2)}
+        fence()
+        eng.batch_upload(ids, mask, sttl, sdp, duration_override=durs, utt_ids=mine)
+        cur["durs"] = durs
+        gather_buf.clear()
+
     if rank == 0:
         B, L, W = eng.batch_dims()
         out = {
@@ -257,11 +382,21 @@ def main():
                        "latent_frames_max": L, "audio_sec_per_step": round(audio_per_step, 2),
                        "weights": "synthetic (descriptor include/stn_arch.h, seed 7)",
                        "in_flight_batches": 1,
+                       "timed_region": f"{args.steps} syntheses of the resident batch as hipGraph replays of the post-duration pipeline ({replays_timed} replays counted); "
+                                       f"{n_warm} untimed warm-up steps (eager, capture, first replay)",
+                       "warmup_steps_run": n_warm,
                        "parallelism": f"utterance-sharded x{world}, RCCL gather of int16 PCM to rank 0 overlapped with the next step" if world > 1 else "single GPU"},
             "p50_latency_ms": round(p50, 3),
-            "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM)",
+            "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM), graph replay",
+            "graph_replays_in_timed_region": replays_timed,
             "roofline": roof,
         }
+        if eager:
+            out["eager_sampled"] = eager
+        if other_scaling:
+            out["other_scaling"] = other_scaling
+        if gather_check:
+            out["gather_check"] = gather_check
         if hostrec:
             el_h = hostrec.pop("elapsed")
             out["value_host"] = round(audio_per_step * args.steps / el_h, 1)
@@ -275,16 +410,11 @@ def main():
                             "on two streams: the estimator phase of one batch fills the CUs the vocoder phase of the other leaves idle); NOT `value`, "
                             "which runs one batch at a time; per-batch latency roughly doubles in this mode"}
             out["host_loop"] = hostrec
-        if graph:
-            graph["value"] = round(audio_per_step * (1 if world == 1 else 1) / (graph["ms_per_step"] * 1e-3), 1) if world == 1 else None
-            graph["note"] = ("same workload as hipGraph replays of the post-duration pipeline; `value` above is the eager timed region "
-                             "because HIP events cannot be recorded inside graph replays on ROCm 7.2")
-            out["graph_replay"] = graph
         if fam_stats:
             tot = sum(v["ms"] for v in fam_stats.values())
             top = sorted(fam_stats.items(), key=lambda kv: -kv[1]["ms"])[:8]
             out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in top}
-            # secondary rooflines from the one fully-profiled warm-up step (per-kernel HIP-event spans, as above):
+            # secondary rooflines from the one fully-profiled step (per-kernel HIP-event spans, as above):
             # GEMM / attention families against dense MFMA peak, the conv / norm families against HBM peak
             other = {}
             for k, v in top:
@@ -315,6 +445,10 @@ def main():
                                         "hbm": {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)},
                                         "mfma": {"achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tfs / peak, 4)},
                                         "note": "event-timed spans of every vo.* launch in one fully profiled step"}
+            st_ms = {}
+            for k, v in fam_stats.items():
+                st_ms[k.split(".")[0]] = st_ms.get(k.split(".")[0], 0.0) + v["ms"]
+            out["stage_ms_fully_profiled_step"] = {k: round(v, 3) for k, v in sorted(st_ms.items())}
         if world == 1 and not args.no_b1 and not args.mixed:
             out["single_utterance"] = single_utterance(eng, arch, up, args)
         if world == 1 and args.cpu_sample > 0:

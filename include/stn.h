@@ -122,10 +122,22 @@ int stn_set_row_layout(stn_handle* h, int packed);
 /* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
  * activation never leaves the registers (bf16 and f16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip
  * idle while each still streams both weight matrices; other shapes keep the two GEMM launches).
- * Bit mask over the stages: 1 = vocoder, 2 = vector estimator, 4 = text encoder / duration predictor; 0 = never.  The default
- * is the set of stages where it measured faster on MI355X.  Same result as the two launches up to fp32
- * summation order (tests/test_gpu_ffn.py). */
+ * Bit mask over the stages: 1 = vocoder, 2 = vector estimator, 4 = text encoder / duration predictor, 8 = the estimator's blocks as
+ * K4-split (see stn_set_fused_ffn_min_rows); 0 = never.  The default (9) is the set of stages where a form measured faster on
+ * MI355X.
+ * WHAT IS AND IS NOT BIT-IDENTICAL.  Which kernel a block runs is decided by the launch's row count (these thresholds; also split-K
+ * for small exact-fp32 GEMMs and the attention grid shape), so an utterance synthesized alone and the same utterance inside a large
+ * batch may run different kernels: they agree to rounding (K4 vs two launches: fp32 summation order and, in f16, the exp2- vs
+ * erf-form GELU; K4-split: 16-bit partial sums), with identical predicted durations to 1e-5 and identical latent lengths
+ * (tests/test_gpu_batch_invariance.py holds recorded bounds).  Within one kernel regime a row's result does not depend on the
+ * number of rows, their order or their position in the launch: packed vs trimmed vs dense vocoder rows, graph replay vs eager and
+ * sharded vs unsharded batches of the same regime are bit-identical (tests/test_gpu_packed.py, tests/test_gpu_ffn.py). */
 int stn_set_fused_ffn(stn_handle* h, int stage_mask);
+/* Row thresholds of the two fused forms (negative: leave unchanged): K4 (stage mask bits 1 / 2 / 4) is taken from k4_rows rows on,
+ * K4-split (bit 8: the estimator's blocks with the hidden dimension cut over four workgroups per 128-row slab and 16-bit partial
+ * sums folded by the next reader of the residual stream) from split_rows rows on.  Below a threshold the block runs as two tiled
+ * GEMM launches; the forms agree to rounding, not bit for bit (tests/test_gpu_ffn.py, tests/test_gpu_batch_invariance.py). */
+int stn_set_fused_ffn_min_rows(stn_handle* h, int64_t k4_rows, int64_t split_rows);
 /* rows the vector estimator worked on in the last stn_batch_run: sum of the latent lengths (packed) or B*L (padded) */
 int64_t stn_batch_ve_rows(const stn_handle* h);
 /* frames the vocoder computed in the last stn_batch_run: B*L*ccf, or fewer when the position-independent part of the padding
@@ -202,13 +214,24 @@ int stn_op_dwconv_ln_ragged(stn_handle* h, int dtype, int B, int L, int C, int k
 int stn_op_attention(stn_handle* h, int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k,
                      const float* v, const int32_t* qlen_or_null, const int32_t* klen_or_null, int rope_mode, float* o);
 /* the pointwise pair of a ConvNeXt block on host operands (16-bit engines): x <- x + gamma * (W2 . GELU(W1 . xn + b1) + b2)
- * [+ rowvec[row_b[m]]], W1 [I,C], W2 [C,I], x [M,C] in place.  fused = 1: the K4 kernel, 0: the two tiled GEMM launches. */
+ * [+ rowvec[row_b[m]]], W1 [I,C], W2 [C,I], x [M,C] in place.  fused = 1: the K4 kernel, 0: the two tiled GEMM launches,
+ * 2: K4-split (16-bit partial sums of the hidden quarters) followed by the fold. */
 int stn_op_ffn(stn_handle* h, int M, int C, int I, const float* xn /*[M,C]*/, const float* W1, const float* b1, const float* W2,
                const float* b2_or_null, const float* gamma_or_null, const float* rowvec_or_null /*[nseq,C]*/,
                const int32_t* row_b_or_null /*[M]*/, int nseq, float* x, int fused);
 /* timing of the same on random device-resident operands.  out5: avg ms per call; fused only: mean shader-clock cycles per
  * workgroup until the first stage landed / in the tile loop / in the epilogue, and the number of workgroups */
 int stn_op_ffn_bench(stn_handle* h, int M, int C, int I, int fused, int iters, double* out5);
+/* fold + depthwise conv + LayerNorm on packed rows (16-bit engines): sequence b owns seqlen[b] consecutive rows, M = their sum;
+ * part [S,M,C] (fp32, rounded to the engine's 16-bit format first).  x_out [M,C] = x + gamma * (sum_s part[s] + b2) + rowvec[b],
+ * y [M,C] = LayerNorm(dwconv_{k,dil}(x_out)) (fp32 copy of the 16-bit output). */
+int stn_op_fold_dwconv_ln(stn_handle* h, int B, int C, int k, int dil, int S, const int32_t* seqlen, const float* x, const float* part,
+                          const float* b2_or_null, const float* gamma_or_null, const float* rowvec_or_null /*[B,C]*/, const float* w /*[C,k]*/,
+                          const float* bias, const float* ln_g, const float* ln_b, float* x_out, float* y);
+/* timing of one estimator-style block on B packed sequences of L frames, random device-resident operands: mode 0 = dwconv_ln + pw1 +
+ * pw2, mode 2 = fold_dwconv_ln + K4-split.  out6: avg ms per block, avg ms of its conv kernel alone; mode 2: mean shader-clock cycles per
+ * fold_dwconv_ln workgroup in phase 1 / at the hand-over barrier / in phase 2, and the launch's span (first entry to last exit) */
+int stn_op_block_bench(stn_handle* h, int B, int L, int C, int I, int k, int dil, int mode, int iters, double* out6);
 int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids_or_null,
                  const int32_t* len_or_null, float* out);
 

@@ -8,7 +8,7 @@ import numpy as np
 from .arch import StnArch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstn.so")
+LIB_PATH = os.environ.get("STN_LIB") or os.path.join(_HERE, "libstn.so")  # STN_LIB: a diagnostic build (timing variants)
 _LIB = None
 
 F32, BF16, F16 = 0, 1, 2
@@ -116,6 +116,9 @@ def load():
     L.stn_op_ffn.argtypes = [vp, ci, ci, ci, _f32p, _f32p, _f32p, _f32p, vp, vp, vp, vp, ci, _f32p, ci]
     L.stn_op_ffn_bench.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     L.stn_set_fused_ffn.argtypes = [vp, ci]
+    L.stn_set_fused_ffn_min_rows.argtypes = [vp, ctypes.c_int64, ctypes.c_int64]
+    L.stn_op_fold_dwconv_ln.argtypes = [vp, ci, ci, ci, ci, ci, _i32p, _f32p, _f32p, vp, vp, vp, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+    L.stn_op_block_bench.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     _LIB = L
     return L
 
@@ -405,13 +408,36 @@ class Engine:
         rba, rbp = _opt(row_b, np.int32)
         b2p = b2a.ctypes.data if b2a is not None else None
         self._ck(self._lib.stn_op_ffn(self._h, M, C, I, _c(xn, np.float32), _c(W1, np.float32), _c(b1, np.float32), _c(W2, np.float32),
-                                      b2p, gp, rvp, rbp, 0 if rva is None else rva.shape[0], out, int(bool(fused))))
+                                      b2p, gp, rvp, rbp, 0 if rva is None else rva.shape[0], out, int(fused)))
         return out
 
     def op_ffn_bench(self, M, C, I, fused=True, iters=20):
+        """fused: 0 / False two launches, 1 / True K4, 2 K4-split (partial sums only; the fold is part of op_block_bench)."""
         out = (ctypes.c_double * 5)()
-        self._ck(self._lib.stn_op_ffn_bench(self._h, M, C, I, int(bool(fused)), iters, out))
+        self._ck(self._lib.stn_op_ffn_bench(self._h, M, C, I, int(fused), iters, out))
         return dict(ms=out[0], first_stage=out[1], tile_loop=out[2], epilogue=out[3], workgroups=int(out[4]))
+
+    def op_fold_dwconv_ln(self, seqlen, x, part, b2, gamma, rowvec, w, bias, g, b, k, dil):
+        """fold + depthwise conv + LayerNorm on packed rows -> (x_out, y)."""
+        seqlen = np.ascontiguousarray(seqlen, np.int32)
+        S, M, C = part.shape
+        xo = np.empty((M, C), np.float32)
+        y = np.empty((M, C), np.float32)
+        b2a, _ = _opt(b2, np.float32)
+        ga, _ = _opt(gamma, np.float32)
+        rva, _ = _opt(rowvec, np.float32)
+        p = lambda a: None if a is None else a.ctypes.data
+        self._ck(self._lib.stn_op_fold_dwconv_ln(self._h, len(seqlen), C, k, dil, S, seqlen, _c(x, np.float32), _c(part, np.float32), p(b2a), p(ga), p(rva),
+                                                 _c(w, np.float32), _c(bias, np.float32), _c(g, np.float32), _c(b, np.float32), xo, y))
+        return xo, y
+
+    def op_block_bench(self, B, L, C, I, k, dil, mode, iters=20):
+        out = (ctypes.c_double * 6)()
+        self._ck(self._lib.stn_op_block_bench(self._h, B, L, C, I, k, dil, mode, iters, out))
+        return dict(ms=out[0], conv_ms=out[1], fold_phase1=out[2], fold_barrier=out[3], fold_phase2=out[4], fold_span=out[5])
+
+    def set_fused_ffn_min_rows(self, k4_rows=-1, split_rows=-1):
+        self._ck(self._lib.stn_set_fused_ffn_min_rows(self._h, int(k4_rows), int(split_rows)))
 
     def op_gemm_phases(self, M, N, K, mode=0, dtype=None):
         out = (ctypes.c_double * 6)()

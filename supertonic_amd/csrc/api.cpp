@@ -251,7 +251,8 @@ int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_m
 int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows() : 0; }
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
-int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 7, "stage mask must be in 0..7"); h->eng->set_fused_ffn(mask); }) }
+int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 15, "stage mask must be in 0..15"); h->eng->set_fused_ffn(mask); }) }
+int stn_set_fused_ffn_min_rows(stn_handle* h, int64_t k4_rows, int64_t split_rows) { STN_TRY(h, { h->eng->set_fused_ffn_min_rows(k4_rows, split_rows); }) }
 int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }
 int64_t stn_graph_replays(const stn_handle* h) { return h ? h->eng->graph_replays() : 0; }
 int64_t stn_graphs_cached(const stn_handle* h) { return h ? (int64_t)h->eng->graphs_cached() : 0; }
@@ -375,11 +376,28 @@ int stn_op_ffn(stn_handle* h, int M, int C, int I, const float* xn, const float*
     STN_TRY(h, { need(M > 0 && C > 0 && I > 0 && C % 8 == 0 && I % 8 == 0 && xn && W1 && b1 && W2 && x, "stn_op_ffn: bad argument");
                  need(!rowvec || nseq > 0, "stn_op_ffn: rowvec needs nseq > 0");
                  if (rowvec && row_b) for (int m = 0; m < M; ++m) need(row_b[m] >= 0 && row_b[m] < nseq, "stn_op_ffn: row_b out of range");
-                 h->eng->op_ffn(M, C, I, xn, W1, b1, W2, b2, gamma, rowvec, row_b, nseq, x, fused != 0); })
+                 need(fused >= 0 && fused <= 2, "stn_op_ffn: mode must be 0 (two launches), 1 (K4) or 2 (K4-split + fold)");
+                 h->eng->op_ffn(M, C, I, xn, W1, b1, W2, b2, gamma, rowvec, row_b, nseq, x, fused); })
 }
 int stn_op_ffn_bench(stn_handle* h, int M, int C, int I, int fused, int iters, double* out5) {
     STN_TRY(h, { need(M > 0 && C > 0 && I > 0 && C % 8 == 0 && I % 8 == 0 && iters > 0 && out5, "stn_op_ffn_bench: bad argument");
-                 h->eng->op_ffn_bench(M, C, I, fused != 0, iters, out5); })
+                 need(fused >= 0 && fused <= 2, "stn_op_ffn_bench: mode must be 0, 1 or 2");
+                 h->eng->op_ffn_bench(M, C, I, fused, iters, out5); })
+}
+int stn_op_fold_dwconv_ln(stn_handle* h, int B, int C, int k, int dil, int S, const int32_t* seqlen, const float* x, const float* part,
+                          const float* b2, const float* gamma, const float* rowvec, const float* w, const float* bias, const float* g,
+                          const float* b, float* x_out, float* y) {
+    STN_TRY(h, { need(B > 0 && C > 0 && C % 8 == 0 && (k == 5 || k == 7) && dil > 0 && S == 4 && seqlen && x && part && w && bias && g && b && x_out && y,
+                      "stn_op_fold_dwconv_ln: bad argument");
+                 int64_t tot = 0;
+                 for (int i = 0; i < B; ++i) { need(seqlen[i] >= 0 && seqlen[i] < (1 << 20), "stn_op_fold_dwconv_ln: seqlen out of range"); tot += seqlen[i]; }
+                 need(tot > 0, "stn_op_fold_dwconv_ln: no rows");
+                 h->eng->op_fold_dwconv_ln(B, C, k, dil, S, seqlen, x, part, b2, gamma, rowvec, w, bias, g, b, x_out, y); })
+}
+int stn_op_block_bench(stn_handle* h, int B, int L, int C, int I, int k, int dil, int mode, int iters, double* out2) {
+    STN_TRY(h, { need(B > 0 && L > 0 && C > 0 && I > 0 && C % 8 == 0 && I % 8 == 0 && (k == 5 || k == 7) && dil > 0 && iters > 0 && out2 && (mode == 0 || mode == 2),
+                      "stn_op_block_bench: bad argument");
+                 h->eng->op_block_bench(B, L, C, I, k, dil, mode, iters, out2); })
 }
 int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int32_t* len, float* out) {
     STN_TRY(h, { need(B > 0 && D > 0 && L > 0 && out, "stn_op_randn: bad argument"); h->eng->op_randn(seed, B, D, L, utt_ids, len, out); })

@@ -116,6 +116,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
+    if (const char* p = getenv("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
 
@@ -532,16 +533,46 @@ void* Engine::to_act(const float* src, int64_t n) {
 
 // x <- (x + gamma * pw2(GELU(pw1(LN(dwconv(x)))))) * mask      (in place, x fp32 [B*L][C])
 void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
-                      const int* conv_len, const float* rowvec, int rv_ld, const Ragged* rg) {
+                      const int* conv_len, const float* rowvec, int rv_ld, const Ragged* rg, FoldState* fs) {
     const int64_t M = rg ? (int64_t)rg->rows : (int64_t)B * L;
     const Arena::Mark mk = ar_.mark();
     void* xn = act_alloc(M * C);
-    if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (is_half(dt_) ? 2.0 : 4.0)));
-    launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, rg ? len : conv_len, rg ? rg->off : nullptr);
-    if (prof_on_) prof_end();
+    if (fs) x = fs->x;
+    if (fs && fs->pending) {
+        // the previous block's pointwise pair is still a set of partial sums: this block's conv kernel folds it on the way in
+        if (prof_on_) prof_begin("fold_dwconv_ln", (double)M * C * (2.0 * k + 8 + 2.0 * fs->fold.S), (double)M * C * (8.0 + 2.0 + 2.0 * fs->fold.S));
+        launch_fold_dwconv_ln(s_, dt_, fs->x, fs->x_alt, B, L, C, fs->fold, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, len, rg->off);
+        if (prof_on_) prof_end();
+        std::swap(fs->x, fs->x_alt);
+        fs->pending = false;
+        x = fs->x;
+    } else {
+        if (prof_on_) prof_begin("dwconv_ln", (double)M * C * (2.0 * k + 8), (double)M * C * (4.0 + (is_half(dt_) ? 2.0 : 4.0)));
+        launch_dwconv_ln(s_, dt_, x, B, L, C, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, rg ? len : conv_len, rg ? rg->off : nullptr);
+        if (prof_on_) prof_end();
+    }
     // K4: pw1 -> GELU -> pw2 -> layer scale + residual in one launch, the hidden activation never leaves the registers
     const int stage_bit = stage_[0] == 'v' && stage_[1] == 'o' ? 1 : (stage_[0] == 'v' ? 2 : 4);
     const auto fw = ffn_w_.find(p.pw1.w.as(dt_));
+    // K4-split (the estimator at batch size: 59 slabs of 128 rows cannot fill 256 CUs, and a workgroup that streams both matrices
+    // for 128 rows is ingest-bound): four workgroups per slab, each over a quarter of the hidden units (a quarter of the weight
+    // stream), 16-bit partial sums; b2, layer scale, residual and time vector are applied by the next reader of x.  The split is a
+    // function of the block's shape only.  Packed rows only (the fold kernels index sequences through row_off).
+    if (fs && rg && (fused_ffn_ & 8) && stage_bit == 2 && fw != ffn_w_.end() && fw->second.wsplit && M >= ffn_split_min_rows_ &&
+        M * C * 2 < 0x7FFFFFFFll && fold_dwconv_ln_supported(C, k, 1 << std::max(0, a_.ve_dilated - 1))) {
+        FfnArgs fa;
+        fa.xn = xn; fa.ldx = C; fa.wseq = fw->second.wsplit; fa.b1 = p.pw1.b; fa.M = (int)M; fa.I = hid;
+        fa.split = fw->second.S; fa.part = fs->part; fa.part_stride = fs->part_stride;
+        if (prof_on_) prof_begin("ffn_split", 4.0 * M * (double)C * hid, (double)M * C * (2.0 + 2.0 * fa.split) + 4.0 * C * hid);
+        launch_ffn_fused(s_, dt_, C, fa);
+        if (prof_on_) prof_end();
+        fs->pending = true;
+        fs->fold = FoldArgs{};
+        fs->fold.part = fs->part; fs->fold.S = fa.split; fs->fold.part_stride = fs->part_stride;
+        fs->fold.b2 = p.pw2.b; fs->fold.gamma = p.gamma; fs->fold.rowvec = rowvec; fs->fold.rv_ld = rv_ld; fs->fold.row_b = rowvec ? rg->row_b : nullptr;
+        ar_.release(mk);
+        return;
+    }
     // ... where it pays: a workgroup streams both weight matrices whatever its share of the rows, so below ~half a chip of
     // 128-row workgroups the two tiled launches win (tools/ffn_bench.py sweep, C = 512: 16384 rows 108 vs 107 us, 20480 rows
     // 116 vs 141 us, 294 rows = one utterance 102 vs 29 us)
@@ -573,6 +604,20 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     e2.row_b = (rg && rowvec) ? rg->row_b : nullptr;
     gemm("gemm_pw2_resid", dt_, u, hid, p.pw2, (int)M, e2);
     ar_.release(mk);
+}
+
+void Engine::fold_layernorm(FoldState& fs, int64_t M, int C, const LNorm& ln, void* xn, const char* tag) {
+    const size_t esz = is_half(dt_) ? 2 : 4;
+    if (fs.pending) {
+        if (prof_on_) prof_begin("fold_ln", (double)M * C * (8 + 2.0 * fs.fold.S), (double)M * C * (8.0 + esz + 2.0 * fs.fold.S));
+        launch_fold_ln(s_, dt_, fs.x, M, C, fs.fold, ln.g, ln.b, a_.ln_eps, xn);
+        if (prof_on_) prof_end();
+        fs.pending = false;
+        return;
+    }
+    if (tag && prof_on_) prof_begin(tag, (double)M * C * 8, (double)M * C * (4.0 + esz));
+    launch_layernorm(s_, dt_, fs.x, M, C, ln.g, ln.b, a_.ln_eps, xn);
+    if (tag && prof_on_) prof_end();
 }
 
 // x <- (x + Wo attn(LN(x) Wq, ctx Wk, ctx Wv)) * mask.   self: ctx = LN(x), one fused QKV GEMM.
@@ -764,8 +809,18 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     const int Dp = (D + 63) / 64 * 64;
     void* z = act_alloc(M * Dp);
     launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z, Dp, llen, roff);
-    float* x = f32_alloc(M * C);
-    Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = x; ein.ldo = C; ein.len = rmask; ein.L = L;
+    FoldState fs;  // the residual stream (and, with K4-split blocks, its pending update)
+    fs.x = f32_alloc(M * C);
+    {
+        const int S = ffn_split_factor(dt_, C, a.ve_hidden);
+        if (rg && S > 1 && (fused_ffn_ & 8) && M >= ffn_split_min_rows_) {
+            fs.x_alt = f32_alloc(M * C);
+            fs.part_stride = ffn_split_rows(M) * C;
+            fs.part = act_alloc(fs.part_stride * S);
+        }
+    }
+    FoldState* const fsp = fs.part ? &fs : nullptr;
+    Epilogue ein; ein.mode = EPI_STORE; ein.out_dtype = F32; ein.out = fs.x; ein.ldo = C; ein.len = rmask; ein.L = L;
     gemm("gemm_in", dt_, z, Dp, linear("ve.in_pad"), (int)M, ein);
     if (!tb) tb = ve_time_cond_dev(B, total_step, current_step);
 
@@ -774,9 +829,8 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         const Attn w = attn_w(p, false);
         const Arena::Mark m2 = ar_.mark();
         void* xn = act_alloc(M * C);
-        if (prof_on_) prof_begin("layernorm", (double)M * C * 8, (double)M * C * (4.0 + esz));
-        launch_layernorm(s_, dt_, x, M, C, w.ln.g, w.ln.b, a.ln_eps, xn);
-        if (prof_on_) prof_end();
+        fold_layernorm(fs, M, C, w.ln, xn, "layernorm");
+        float* const x = fs.x;
         void* qb = act_alloc(M * C);
         Epilogue e; e.mode = EPI_STORE; e.out_dtype = dt_; e.out = qb; e.ldo = C;
         gemm("gemm_q", dt_, xn, C, w.q, (int)M, e);
@@ -800,20 +854,19 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         // the time conditioning x += tb[b] rides in the residual epilogue of the last dilated block (was a separate pass)
         for (int j = 0; j < a.ve_dilated; ++j) {
             const bool last = j == a.ve_dilated - 1;
-            convnext(convnext_w(p + ".dil" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1 << j, llen, nullptr,
-                     last ? tb + (size_t)blk * C : nullptr, nb * C, rg);
+            convnext(convnext_w(p + ".dil" + std::to_string(j)), fs.x, B, L, C, a.ve_hidden, a.ve_kernel, 1 << j, llen, nullptr,
+                     last ? tb + (size_t)blk * C : nullptr, nb * C, rg, fsp);
         }
-        if (a.ve_dilated == 0) launch_add_rowvec(s_, x, tb + (size_t)blk * C, nb * C, B, L, C, llen);  // (padded layout only)
-        convnext(convnext_w(p + ".cn_a"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg);
+        if (a.ve_dilated == 0) launch_add_rowvec(s_, fs.x, tb + (size_t)blk * C, nb * C, B, L, C, llen);  // (padded layout only)
+        convnext(convnext_w(p + ".cn_a"), fs.x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg, fsp);
         cross(p + ".text", c.text_kv, blk, c.Lt, tlen, 1);
-        convnext(convnext_w(p + ".cn_b"), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg);
+        convnext(convnext_w(p + ".cn_b"), fs.x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg, fsp);
         cross(p + ".style", c.style_kv, blk, a.n_style_ttl, nullptr, -1);
     }
     for (int j = 0; j < a.ve_tail_blocks; ++j)
-        convnext(convnext_w("ve.tail" + std::to_string(j)), x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg);
+        convnext(convnext_w("ve.tail" + std::to_string(j)), fs.x, B, L, C, a.ve_hidden, a.ve_kernel, 1, llen, nullptr, nullptr, 0, rg, fsp);
     void* xn = act_alloc(M * C);
-    const LNorm ln = lnorm("ve.out_ln");
-    launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
+    fold_layernorm(fs, M, C, lnorm("ve.out_ln"), xn, nullptr);
     // Euler update fused into the output projection; dt[b] = 1 / total_step[b]
     const float* dtv = dt;
     if (!dtv) {
@@ -858,7 +911,17 @@ void Engine::prepare_ffn_weights() {
         }
         launch_ffn_pack(s_, c.pw1.w.as(dt_), c.pw2.w.as(dt_), C, hid, tmp, wseq);
         sync();  // tmp is reused by the next block
-        ffn_w_[c.pw1.w.as(dt_)] = FfnW{wseq};
+        FfnW fw; fw.wseq = wseq;
+        const int S = p.compare(0, 3, "ve.") == 0 ? ffn_split_factor(dt_, C, hid) : 0;  // the estimator's blocks also as hidden-split streams
+        if (S > 1) {
+            void* ws = nullptr;
+            STN_HIP(hipMalloc(&ws, (size_t)2 * hid * C * 2));
+            owned_.push_back(ws);
+            launch_ffn_pack(s_, c.pw1.w.as(dt_), c.pw2.w.as(dt_), C, hid, tmp, ws, S);
+            sync();
+            fw.wsplit = ws; fw.S = S;
+        }
+        ffn_w_[c.pw1.w.as(dt_)] = fw;
     };
     auto S = [](const char* fmt, int i, int j = 0) { char b[64]; snprintf(b, sizeof b, fmt, i, j); return std::string(b); };
     for (int i = 0; i < a.dp_conv_blocks; ++i) add(S("dp.conv%d", i), a.dp_dim, a.dp_hidden);
@@ -1638,10 +1701,12 @@ void Engine::op_gemm_phases(int dtype, int M, int N, int K, int mode, double* ou
 }
 
 void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma,
-                    const float* rowvec, const int* row_b, int nseq, float* x, bool fused) {
+                    const float* rowvec, const int* row_b, int nseq, float* x, int mode) {
     STN_HIP(hipSetDevice(device_));
+    const bool fused = mode != 0;
     if (!is_half(dt_)) throw std::invalid_argument("op_ffn: 16-bit engines only");
     if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn: shape not supported by the fused kernel");
+    if (mode == 2 && ffn_split_factor(dt_, C, I) < 2) throw std::invalid_argument("op_ffn: shape not supported by the hidden-split kernel");
     ar_.reset();
     float* d_xn = up(ar_, s_, xn, (size_t)M * C);
     float* d_w1 = up(ar_, s_, W1, (size_t)I * C);
@@ -1661,11 +1726,26 @@ void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const
     if (fused) {
         void* tmp = act_alloc((int64_t)2 * I * C);
         void* wseq = act_alloc((int64_t)2 * I * C);
-        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq);
+        const int S = mode == 2 ? ffn_split_factor(dt_, C, I) : 1;
+        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
         FfnArgs fa;
         fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
         fa.M = M; fa.I = I; fa.rowvec = d_rv; fa.rv_ld = C; fa.row_b = d_rb; fa.L = M;
-        launch_ffn_fused(s_, dt_, C, fa);
+        if (mode == 2) {
+            fa.split = S; fa.part_stride = ffn_split_rows(M) * C; fa.part = act_alloc(fa.part_stride * S);
+            launch_ffn_fused(s_, dt_, C, fa);
+            // the pending update, folded by the LayerNorm form of the fold (its normalised output is not part of this op)
+            float* ones = f32_alloc(C);
+            launch_fill(s_, ones, C, 1.f);
+            float* zeros = f32_alloc(C);
+            launch_fill(s_, zeros, C, 0.f);
+            FoldArgs fo; fo.part = fa.part; fo.S = S; fo.part_stride = fa.part_stride; fo.b2 = d_b2 ? d_b2 : zeros; fo.gamma = d_g ? d_g : ones;
+            fo.rowvec = d_rv; fo.rv_ld = C; fo.row_b = d_rb;
+            void* y = act_alloc((int64_t)M * C);
+            launch_fold_ln(s_, dt_, d_x, M, C, fo, ones, ones, a_.ln_eps, y);
+        } else {
+            launch_ffn_fused(s_, dt_, C, fa);
+        }
     } else {
         void* u = act_alloc((int64_t)M * I);
         Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
@@ -1678,8 +1758,11 @@ void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const
     sync();
 }
 
-void Engine::op_ffn_bench(int M, int C, int I, bool fused, int iters, double* out5) {
+void Engine::op_ffn_bench(int M, int C, int I, int mode, int iters, double* out5) {
     STN_HIP(hipSetDevice(device_));
+    const bool fused = mode != 0;
+    const int S = mode == 2 ? ffn_split_factor(dt_, C, I) : 1;
+    if (mode == 2 && S < 2) throw std::invalid_argument("op_ffn_bench: shape not supported by the hidden-split kernel");
     if (!is_half(dt_)) throw std::invalid_argument("op_ffn_bench: 16-bit engines only");
     if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn_bench: shape not supported by the fused kernel");
     ar_.reset();
@@ -1706,16 +1789,20 @@ void Engine::op_ffn_bench(int M, int C, int I, bool fused, int iters, double* ou
     if (fused) {
         void* tmp = act_alloc((int64_t)2 * I * C);
         wseq = act_alloc((int64_t)2 * I * C);
-        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq);
+        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
     }
     void* u = fused ? nullptr : act_alloc((int64_t)M * I);
-    const int nwg = (M + 127) / 128;
+    const int64_t pstride = ffn_split_rows(M) * C;
+    void* part = mode == 2 ? act_alloc(pstride * S) : nullptr;
+    const int nslab = (M + 127) / 128;
+    const int nwg = mode == 2 ? (nslab + 7) / 8 * 8 * S : nslab;
     unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
     auto run = [&](unsigned long long* stamps) {
         if (fused) {
             FfnArgs fa;
             fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
             fa.M = M; fa.I = I; fa.L = M; fa.ts = stamps;
+            if (mode == 2) { fa.split = S; fa.part = part; fa.part_stride = pstride; }
             launch_ffn_fused(s_, dt_, C, fa);
         } else {
             Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
@@ -1737,13 +1824,157 @@ void Engine::op_ffn_bench(int M, int C, int I, bool fused, int iters, double* ou
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     out5[0] = ms / iters;
     if (fused) {
+        STN_HIP(hipMemsetAsync(ts, 0, sizeof(unsigned long long) * 4 * (size_t)nwg, s_));
         run(ts);
         std::vector<unsigned long long> h((size_t)4 * nwg);
         STN_HIP(hipMemcpyAsync(h.data(), ts, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s_));
         sync();
         double s1 = 0, s2 = 0, s3 = 0;
-        for (int w = 0; w < nwg; ++w) { s1 += (double)(h[4 * w + 1] - h[4 * w]); s2 += (double)(h[4 * w + 2] - h[4 * w + 1]); s3 += (double)(h[4 * w + 3] - h[4 * w + 2]); }
-        out5[1] = s1 / nwg; out5[2] = s2 / nwg; out5[3] = s3 / nwg; out5[4] = nwg;
+        int live = 0;  // (workgroups of a hidden-split grid beyond the last slab exit at once and leave no stamps)
+        for (int w = 0; w < nwg; ++w) {
+            if (!h[4 * w + 3]) continue;
+            ++live;
+            s1 += (double)(h[4 * w + 1] - h[4 * w]); s2 += (double)(h[4 * w + 2] - h[4 * w + 1]); s3 += (double)(h[4 * w + 3] - h[4 * w + 2]);
+        }
+        if (live) { out5[1] = s1 / live; out5[2] = s2 / live; out5[3] = s3 / live; }
+        out5[4] = live;
+    }
+    STN_HIP(hipGetLastError());
+    sync();
+}
+
+void Engine::op_fold_dwconv_ln(int B, int C, int k, int dil, int S, const int* seqlen, const float* x, const float* part, const float* b2,
+                               const float* gamma, const float* rowvec, const float* w, const float* bias, const float* g, const float* b,
+                               float* x_out, float* y) {
+    STN_HIP(hipSetDevice(device_));
+    if (!is_half(dt_)) throw std::invalid_argument("op_fold_dwconv_ln: 16-bit engines only");
+    ar_.reset();
+    std::vector<int> off(B + 1, 0);
+    int L = 0;
+    for (int i = 0; i < B; ++i) { off[i + 1] = off[i] + seqlen[i]; L = std::max(L, seqlen[i]); }
+    const int64_t M = off[B];
+    const size_t n = (size_t)M * C;
+    std::vector<float> wt((size_t)C * k);
+    for (int c = 0; c < C; ++c) for (int j = 0; j < k; ++j) wt[(size_t)j * C + c] = w[(size_t)c * k + j];
+    const int* dlen = up(ar_, s_, seqlen, (size_t)B);
+    const int* doff = up(ar_, s_, off.data(), (size_t)B + 1);
+    float* dx = up(ar_, s_, x, n);
+    float* dp32 = up(ar_, s_, part, n * S);
+    float* db2 = b2 ? up(ar_, s_, b2, (size_t)C) : nullptr;
+    float* dgm = gamma ? up(ar_, s_, gamma, (size_t)C) : nullptr;
+    float* drv = rowvec ? up(ar_, s_, rowvec, (size_t)B * C) : nullptr;
+    float* dw = up(ar_, s_, wt.data(), wt.size());
+    float* db = up(ar_, s_, bias, (size_t)C);
+    float* dg = up(ar_, s_, g, (size_t)C);
+    float* dbt = up(ar_, s_, b, (size_t)C);
+    void* dp16 = act_alloc((int64_t)n * S);
+    launch_cast(s_, dt_, dp32, (int64_t)n * S, dp16);
+    float* dxo = f32_alloc((int64_t)n);
+    void* dy = act_alloc((int64_t)n);
+    float* dy32 = f32_alloc((int64_t)n);
+    float* ones = f32_alloc(C);
+    launch_fill(s_, ones, C, 1.f);
+    float* zeros = f32_alloc(C);
+    launch_fill(s_, zeros, C, 0.f);
+    FoldArgs fo; fo.part = dp16; fo.S = S; fo.part_stride = (int64_t)n; fo.b2 = db2 ? db2 : zeros; fo.gamma = dgm ? dgm : ones; fo.rowvec = drv; fo.rv_ld = C;
+    launch_fold_dwconv_ln(s_, dt_, dx, dxo, B, L, C, fo, dw, db, k, dil, dg, dbt, 1e-6f, dy, dlen, doff);
+    launch_half_to_f32(s_, dt_, dy, (int64_t)n, dy32);
+    STN_HIP(hipGetLastError());
+    STN_HIP(hipMemcpyAsync(x_out, dxo, n * 4, hipMemcpyDeviceToHost, s_));
+    STN_HIP(hipMemcpyAsync(y, dy32, n * 4, hipMemcpyDeviceToHost, s_));
+    sync();
+}
+
+void Engine::op_block_bench(int B, int L, int C, int I, int k, int dil, int mode, int iters, double* out2) {
+    STN_HIP(hipSetDevice(device_));
+    if (!is_half(dt_)) throw std::invalid_argument("op_block_bench: 16-bit engines only");
+    const int S = ffn_split_factor(dt_, C, I);
+    if (mode == 2 && S < 2) throw std::invalid_argument("op_block_bench: shape not supported by the hidden-split kernel");
+    ar_.reset();
+    for (int i = 0; i < 6; ++i) out2[i] = 0.0;
+    const int64_t M = (int64_t)B * L;
+    std::vector<int> len(B, L), off(B + 1);
+    for (int i = 0; i <= B; ++i) off[i] = i * L;
+    const int* dlen = up(ar_, s_, len.data(), (size_t)B);
+    const int* doff = up(ar_, s_, off.data(), (size_t)B + 1);
+    float* xa = f32_alloc(M * C);
+    float* xb = f32_alloc(M * C);
+    launch_randn_masked(s_, 11, nullptr, 1, (int)M, C, nullptr, xa);
+    float* wr = f32_alloc((int64_t)I * C);
+    launch_randn_masked(s_, 12, nullptr, 1, I, C, nullptr, wr);
+    launch_scale(s_, wr, I * C, 0.05f);
+    void* w1_16 = act_alloc((int64_t)I * C);
+    void* w2_16 = act_alloc((int64_t)I * C);
+    launch_cast(s_, dt_, wr, (int64_t)I * C, w1_16);
+    launch_cast(s_, dt_, wr, (int64_t)I * C, w2_16);
+    float* d_b1 = f32_alloc(I);
+    float* d_b2 = f32_alloc(C);
+    float* d_g = f32_alloc(C);
+    float* d_one = f32_alloc(C);
+    float* dwt = f32_alloc((int64_t)k * C);
+    launch_fill(s_, d_b1, I, 0.01f); launch_fill(s_, d_b2, C, 0.01f); launch_fill(s_, d_g, C, 0.01f); launch_fill(s_, d_one, C, 1.f);
+    launch_fill(s_, dwt, k * C, 1.f / k);
+    void* xn = act_alloc(M * C);
+    void* u = mode == 2 ? nullptr : act_alloc(M * I);
+    void* wseq = nullptr;
+    const int64_t pstride = ffn_split_rows(M) * C;
+    void* part = nullptr;
+    if (mode == 2) {
+        void* tmp = act_alloc((int64_t)2 * I * C);
+        wseq = act_alloc((int64_t)2 * I * C);
+        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
+        part = act_alloc(pstride * S);
+        STN_HIP(hipMemsetAsync(part, 0, (size_t)pstride * S * 2, s_));
+    }
+    FoldArgs fo; fo.part = part; fo.S = S; fo.part_stride = pstride; fo.b2 = d_b2; fo.gamma = d_g;
+    auto conv = [&]() {
+        if (mode == 2) { launch_fold_dwconv_ln(s_, dt_, xa, xb, B, L, C, fo, dwt, d_b2, k, dil, d_one, d_b2, 1e-6f, xn, dlen, doff); std::swap(xa, xb); }
+        else launch_dwconv_ln(s_, dt_, xa, B, L, C, dwt, d_b2, k, dil, d_one, d_b2, 1e-6f, xn, dlen, doff);
+    };
+    auto block = [&]() {
+        conv();
+        if (mode == 2) {
+            FfnArgs fa; fa.xn = xn; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.M = (int)M; fa.I = I; fa.split = S; fa.part = part; fa.part_stride = pstride;
+            launch_ffn_fused(s_, dt_, C, fa);
+        } else {
+            Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
+            launch_gemm(s_, dt_, xn, C, w1_16, C, (int)M, I, C, e1);
+            Epilogue e2; e2.mode = EPI_RESID; e2.resid = xa; e2.ldo = C; e2.gamma = d_g; e2.bias = d_b2; e2.L = (int)M;
+            launch_gemm(s_, dt_, u, I, w2_16, I, (int)M, C, I, e2);
+        }
+    };
+    hipEvent_t a, b;
+    STN_HIP(hipEventCreate(&a)); STN_HIP(hipEventCreate(&b));
+    for (int which = 0; which < 2; ++which) {
+        for (int i = 0; i < 3; ++i) { if (which) conv(); else block(); }
+        STN_HIP(hipEventRecord(a, s_));
+        for (int i = 0; i < iters; ++i) { if (which) conv(); else block(); }
+        STN_HIP(hipEventRecord(b, s_));
+        STN_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        STN_HIP(hipEventElapsedTime(&ms, a, b));
+        out2[which] = ms / iters;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (mode == 2) {  // phase stamps of one fold_dwconv_ln launch
+        const int nwg = B * ((L + 31) / 32);
+        unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
+        STN_HIP(hipMemsetAsync(ts, 0, sizeof(unsigned long long) * 4 * (size_t)nwg, s_));
+        fo.ts = ts;
+        conv();
+        fo.ts = nullptr;
+        std::vector<unsigned long long> h((size_t)4 * nwg);
+        STN_HIP(hipMemcpyAsync(h.data(), ts, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s_));
+        sync();
+        double p1 = 0, p2 = 0, p3 = 0; int live = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int w = 0; w < nwg; ++w) {
+            if (!h[4 * w + 3]) continue;
+            ++live;
+            p1 += (double)(h[4 * w + 1] - h[4 * w]); p2 += (double)(h[4 * w + 2] - h[4 * w + 1]); p3 += (double)(h[4 * w + 3] - h[4 * w + 2]);
+            tmin = std::min(tmin, h[4 * w]); tmax = std::max(tmax, h[4 * w + 3]);
+        }
+        if (live) { out2[2] = p1 / live; out2[3] = p2 / live; out2[4] = p3 / live; out2[5] = (double)(tmax - tmin); }
     }
     STN_HIP(hipGetLastError());
     sync();

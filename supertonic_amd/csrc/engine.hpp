@@ -116,7 +116,7 @@ class Engine {
     int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
     void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
-    struct FfnW { const void* wseq = nullptr; };
+    struct FfnW { const void* wseq = nullptr; const void* wsplit = nullptr; int S = 0; };  // wsplit: the hidden-split stage streams (S = ffn_split_factor)
     std::unordered_map<const void*, FfnW> ffn_w_;  // key: the block's row-major 16-bit pw1 matrix
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
@@ -168,7 +168,14 @@ class Engine {
     void set_packed_rows(bool on) { packed_ve_ = on; }
     // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
     // 4 = text encoder / duration predictor.  bf16 engines, widths 256 / 384 / 512 (ffn_fused_supported)
+    // 8 = the estimator's blocks as K4-split (hidden dimension cut over 4 workgroups per 128-row slab, 16-bit partial sums folded
+    // by the next reader of x: fold_dwconv_ln / fold_ln); packed rows, from ffn_split_min_rows() rows on
     void set_fused_ffn(int mask) { fused_ffn_ = mask; }
+    void set_fused_ffn_min_rows(int64_t k4_rows, int64_t split_rows) {
+        sync(); drop_graphs();  // a captured pipeline has the kernel choice baked in
+        if (k4_rows >= 0) ffn_min_rows_ = k4_rows;
+        if (split_rows >= 0) ffn_split_min_rows_ = split_rows;
+    }
     int fused_ffn() const { return fused_ffn_; }
     int64_t last_ve_rows() const { return last_ve_rows_; }
     int64_t last_vo_rows() const { return last_vo_rows_; }  // frames the vocoder computed in the last batch_run  // rows the estimator worked on in the last batch_run
@@ -222,12 +229,21 @@ class Engine {
     void op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out);
     // K4 on host operands: x <- x + gamma * (W2 . GELU(W1 . xn + b1) + b2) [+ rowvec[row_b[m]]]; xn is rounded to the engine's
     // 16-bit format first.  fused = false runs the two tiled GEMM launches on the same operands (the pair K4 replaces).
+    // mode: 0 = two tiled launches, 1 = K4, 2 = K4-split (partial sums) + fold_ln
     void op_ffn(int M, int C, int I, const float* xn, const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma,
-                const float* rowvec /* [nseq][C] or null */, const int* row_b /* host [M] or null */, int nseq, float* x, bool fused);
+                const float* rowvec /* [nseq][C] or null */, const int* row_b /* host [M] or null */, int nseq, float* x, int mode);
+    // fold_dwconv_ln on host operands (packed rows: sequence b owns seqlen[b] consecutive rows; M = sum): part [S][M][C] fp32 is rounded
+    // to the engine's 16-bit format first.  x_out <- folded x, y <- LayerNorm(dwconv(folded x)) as fp32.
+    void op_fold_dwconv_ln(int B, int C, int k, int dil, int S, const int* seqlen, const float* x, const float* part, const float* b2,
+                           const float* gamma, const float* rowvec /* [B][C] or null */, const float* w /*[C][k]*/, const float* bias,
+                           const float* g, const float* b, float* x_out, float* y);
     // device-resident timing of the block's pointwise pair on random operands: out[0] = avg ms per call (fused: one launch,
     // unfused: pw1 + pw2); fused only: out[1..3] = mean cycles per workgroup to the first stage / in the tile loop / in the
     // epilogue, out[4] = workgroups
-    void op_ffn_bench(int M, int C, int I, bool fused, int iters, double* out5);
+    void op_ffn_bench(int M, int C, int I, int mode, int iters, double* out5);
+    // device-resident timing of one estimator-style block chain on packed rows of B equal sequences of L frames:
+    // mode 0: dwconv_ln + pw1 + pw2;  mode 2: fold_dwconv_ln + K4-split.  out[0] = avg ms per block, out[1] = avg ms of the conv kernel alone, out[2..5] = fold_dwconv_ln phase cycles (mode 2)
+    void op_block_bench(int B, int L, int C, int I, int k, int dil, int mode, int iters, double* out6);
 
     Arena& arena() { return ar_; }
 
@@ -249,8 +265,20 @@ class Engine {
     float* f32_alloc(int64_t n) { return static_cast<float*>(ar_.alloc((size_t)n * 4)); }
     void gemm(const char* tag, int dt, const void* A, int lda, const Linear& w, int M, Epilogue e);
     // rowvec (optional, [B][rv_ld]): added to every row of sequence b in the same residual epilogue (time conditioning)
+    // The residual stream of a stage whose blocks may run as K4-split: x plus at most one pending (unfolded) update.
+    struct FoldState {
+        float* x = nullptr;      // current residual rows
+        float* x_alt = nullptr;  // second buffer: fold_dwconv_ln writes the folded stream there and the two swap
+        void* part = nullptr;    // [S][rows padded to 128][C] 16-bit partial sums (one buffer: its reader runs before the next writer)
+        int64_t part_stride = 0;
+        bool pending = false;
+        FoldArgs fold;           // the pending update
+    };
+    // fs (optional): x is fs->x; the block may leave its pointwise pair pending in fs (the caller folds it with the next reader of x)
     void convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid, int k, int dil, const int* len,
-                  const int* conv_len = nullptr, const float* rowvec = nullptr, int rv_ld = 0, const Ragged* rg = nullptr);
+                  const int* conv_len = nullptr, const float* rowvec = nullptr, int rv_ld = 0, const Ragged* rg = nullptr, FoldState* fs = nullptr);
+    // LayerNorm of the stage's residual stream into xn, folding a pending update first
+    void fold_layernorm(FoldState& fs, int64_t M, int C, const LNorm& ln, void* xn, const char* tag);
     void attn_block(const Attn& p, float* x, int B, int Lq, int C, int H, const void* ctx, int Lk, const int* qlen,
                     const int* klen, int rope_mode, bool self, const Ragged* qrg = nullptr);
     void* to_act(const float* src, int64_t n);
@@ -316,7 +344,8 @@ class Engine {
     bool copied_valid_ = false;
     int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
-    int fused_ffn_ = 1;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
+    int64_t ffn_split_min_rows_ = 4096;  // K4-split only from this many rows on; STN_FFN_SPLIT_MIN_ROWS overrides
+    int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }

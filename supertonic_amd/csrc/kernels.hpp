@@ -123,16 +123,46 @@ struct FfnArgs {
     const float* rowvec = nullptr; int rv_ld = 0; // per-sequence vector added to every row (time conditioning) or null
     const int* len = nullptr; int L = 1;          // padded rows: row m = b*L + t is zeroed when t >= len[b] (null: no mask)
     unsigned long long* ts = nullptr;             // diagnostics: 4 shader-clock stamps per workgroup (entry, first stage, loop, end)
+    // hidden split (ffn_split_factor(C, I) = S > 1): S workgroups per 128-row slab, each over I/S hidden units; wseq packed with
+    // the same S (launch_ffn_pack); the result is NOT applied to x: part[sp][m][:] (16-bit, [S][part_stride / C rows][C]) receives
+    // W2[:, hidden share sp] . GELU(W1[hidden share sp] . xn[m] + b1) and launch_fold_ln / launch_fold_dwconv_ln fold
+    // x <- x + gamma * (sum_sp part[sp] + b2) + rowvec into the residual stream.  b2 / gamma / x / rowvec / len are unused here.
+    int split = 1;
+    void* part = nullptr;                         // rows padded to a multiple of 128
+    int64_t part_stride = 0;                      // elements between two splits (= padded rows * C)
 };
 bool ffn_fused_supported(int dtype, int C, int I);
+// hidden-split factor of the K4-split form for this block shape (0: not supported).  A function of (C, I) ONLY: a row's result
+// must not depend on the number of rows in the launch.
+int ffn_split_factor(int dtype, int C, int I);
+inline int64_t ffn_split_rows(int64_t M) { return (M + 127) / 128 * 128; }
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a);
+// The pending update of a K4-split launch, folded by the next reader of x:
+//   x_new[m] = x[m] + gamma * (((part[0][m] + part[1][m]) + part[2][m]) + ... + b2) + rowvec[seq(m)]      (fp32, this order)
+struct FoldArgs {
+    const void* part = nullptr; int S = 0; int64_t part_stride = 0;   // 16-bit partial sums (the engine's activation format)
+    const float* b2 = nullptr;        // [C] or null
+    const float* gamma = nullptr;     // [C] or null (1)
+    const float* rowvec = nullptr; int rv_ld = 0;  // per-sequence vector or null
+    const int* row_b = nullptr;       // fold_ln with rowvec: sequence of row m
+    unsigned long long* ts = nullptr; // diagnostics (fold_dwconv_ln): 4 shader-clock stamps per workgroup — entry, phase 1 done, hand-over, end
+};
+// x (in place) <- folded x;  y <- LayerNorm(folded x)       (rows are independent)
+void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, const FoldArgs& f, const float* g, const float* b, float eps, void* y);
+// packed rows only (row_off / seqlen as launch_dwconv_ln): x_out <- folded x_in (x_out != x_in: a workgroup re-folds the halo rows
+// of its neighbours);  y <- LayerNorm(dwconv(folded x)).  k = 5 or 7, C % 8 == 0, C <= 512.
+bool fold_dwconv_ln_supported(int C, int k, int dil);
+void launch_fold_dwconv_ln(hipStream_t s, int act_dtype, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
+                           const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y, const int* seqlen,
+                           const int* row_off);
 // W [N][K] row-major 16-bit -> A fragments whose k order matches a GELU'd accumulator used as the B operand (N % 32, K % 32 == 0)
 void launch_repack_frag_acc(hipStream_t s, const void* W, int N, int K, void* Wf);
 // W1 [I][C], W2 [C][I] (row-major 16-bit) -> wseq: hidden tile t of W1 as C/16 KiB fragment pieces, hidden tile t of W2 as
 // C/16 KiB pieces in the accumulator-operand order, laid out as the stage sequence W1(0), W1(1), W2(0), W1(2), W2(1), ...,
 // W1(T-1), W2(T-2), W2(T-1) (T = I/32): the kernel's LDS-DMA stream is then one linear walk through memory.
 // tmp: 2 * I * C 16-bit values of scratch.
-void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq);
+// S > 1 (hidden split): S such streams one after another, stream sp over hidden tiles [sp*T/S, (sp+1)*T/S).
+void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq, int S = 1);
 
 // depthwise 'same' conv (taps k, dilation dil, weights TRANSPOSED [k][C]) fused with LayerNorm over C.
 // x fp32 [B*L][C] -> y act [B*L][C].  C % 4 == 0, C <= 1024.

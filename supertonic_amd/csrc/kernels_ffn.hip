@@ -168,33 +168,48 @@ void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf) {
     STN_KLAUNCH(repack_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const uint16_t*>(W), N, K, static_cast<uint16_t*>(Wf));
 }
 
-void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq) {
-    if (C % 64 || I % 64) throw std::invalid_argument("launch_ffn_pack: C % 64 and I % 64 must be 0");
-    const size_t SB = (size_t)C * 64, T = (size_t)I / 32;
+void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I, void* tmp, void* wseq, int S) {
+    if (C % 64 || I % 64 || S < 1 || (I / 32) % (2 * S)) throw std::invalid_argument("launch_ffn_pack: C % 64, I % 64 and (I / 32) % (2 S) must be 0");
+    const size_t SB = (size_t)C * 64, T = (size_t)I / 32 / S;  // T: hidden tiles per stream
     unsigned char* t1 = static_cast<unsigned char*>(tmp);
     unsigned char* t2 = t1 + (size_t)I * C * 2;
     launch_repack_frag(s, W1, I, C, t1);       // hidden tile t = bytes [t*SB, (t+1)*SB)
     launch_repack_frag_acc(s, W2, C, I, t2);   // likewise
     unsigned char* out = static_cast<unsigned char*>(wseq);
-    for (size_t v = 0; v < 2 * T; ++v) {
-        const bool w2 = v == 2 * T - 1 || (v >= 2 && (v & 1) == 0);
-        const size_t tile = v == 0 ? 0 : v == 2 * T - 1 ? T - 1 : w2 ? (v - 2) / 2 : (v + 1) / 2;
-        stn_check_hip(hipMemcpyAsync(out + v * SB, (w2 ? t2 : t1) + tile * SB, SB, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(ffn_pack)");
-    }
+    for (size_t sp = 0; sp < (size_t)S; ++sp)
+        for (size_t v = 0; v < 2 * T; ++v) {
+            const bool w2 = v == 2 * T - 1 || (v >= 2 && (v & 1) == 0);
+            const size_t tile = sp * T + (v == 0 ? 0 : v == 2 * T - 1 ? T - 1 : w2 ? (v - 2) / 2 : (v + 1) / 2);
+            stn_check_hip(hipMemcpyAsync(out + (sp * 2 * T + v) * SB, (w2 ? t2 : t1) + tile * SB, SB, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(ffn_pack)");
+        }
+}
+
+// LDS of one workgroup: the 4-stage ring, b2 / gamma / b1 behind it; the split form's epilogue re-uses it as four wave-private
+// row images of 32 x (2C + 16) bytes
+static size_t ffn_lds_bytes(int C, int I) {
+    const size_t ring = (size_t)4 * C * 64 + (size_t)(I + 2 * C) * 4, img = (size_t)4 * 32 * (C * 2 + 16);
+    return ring > img ? ring : img;
 }
 
 bool ffn_fused_supported(int dtype, int C, int I) {
-    return is_half(dtype) && (C == 384 || C == 512) && I % 64 == 0 && I >= 128 && I <= 8192;
+    return is_half(dtype) && (C == 384 || C == 512) && I % 64 == 0 && I >= 128 && I <= 8192 && ffn_lds_bytes(C, I) <= 160 * 1024;
+}
+
+int ffn_split_factor(int dtype, int C, int I) {
+    // the estimator's block (C = 384, I = 1536): four workgroups per 128-row slab, 12 hidden tiles each
+    if (!ffn_fused_supported(dtype, C, I) || C != 384 || I < 1024 || (I / 32) % 8) return 0;
+    return 4;
 }
 
 template <int C>
 static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
-    const size_t lds = (size_t)4 * C * 64 + (size_t)(a.I + 2 * C) * 4;
+    const size_t lds = ffn_lds_bytes(C, a.I);
     static PerDeviceOnce attr_once;
     if (attr_once.need())
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024), "hipFuncSetAttribute(ffn_fused)");
-    const dim3 grid((unsigned)((a.M + 127) / 128));
+    const int nslab = (a.M + 127) / 128;
+    const dim3 grid(a.split > 1 ? (unsigned)((nslab + 7) / 8 * 8 * a.split) : (unsigned)nslab);
 #ifdef STN_FFN_VARIANTS
     static const int var = [] { const char* e = getenv("STN_FFN_VAR"); return e ? atoi(e) : 0; }();
     auto go = [&](auto kern) {
@@ -221,8 +236,12 @@ static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a) {
     if (a.M <= 0) return;
     if (!ffn_fused_supported(dtype, C, a.I)) throw std::invalid_argument("launch_ffn_fused: unsupported shape or dtype");
-    if ((size_t)a.M * a.ldx * 2 >= 0x7FFFFFFFull || a.ldx % 8 || a.ldo % 4 || (reinterpret_cast<uintptr_t>(a.xn) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.rowvec && (a.rv_ld % 4 || (reinterpret_cast<uintptr_t>(a.rowvec) & 15))))
+    if (a.split > 1 && (a.split != ffn_split_factor(dtype, C, a.I) || !a.part || a.part_stride < ffn_split_rows(a.M) * C ||
+                        (reinterpret_cast<uintptr_t>(a.part) & 15)))
+        throw std::invalid_argument("launch_ffn_fused: hidden split needs split == ffn_split_factor(C, I) and a 16-byte aligned part buffer of [split][rows padded to 128][C]");
+    if (a.split <= 1 && a.part) throw std::invalid_argument("launch_ffn_fused: part without split");
+    if ((size_t)a.M * a.ldx * 2 >= 0x7FFFFFFFull || a.ldx % 8 || (reinterpret_cast<uintptr_t>(a.xn) & 15) ||
+        (a.split <= 1 && (a.ldo % 4 || !a.x || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.rowvec && (a.rv_ld % 4 || (reinterpret_cast<uintptr_t>(a.rowvec) & 15))))))
         throw std::invalid_argument("launch_ffn_fused: operand alignment / size violates the kernel contract");
     if (C == 384) launch_ffn_t<384>(s, dtype, a);
     else launch_ffn_t<512>(s, dtype, a);

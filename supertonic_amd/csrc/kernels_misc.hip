@@ -48,6 +48,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// sum over each half of the wavefront (lanes 0-31 / 32-63), result in every lane of the half: four DPP steps inside a row of 16
+// (quad swaps, half-row mirror, row mirror) and one swizzle across the two rows — no LDS-crossbar round trip per step
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+    const int iv = __float_as_int(v);
+    int o;
+    switch (ctrl_sel) {
+        case 0: o = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+        case 1: o = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+        case 2: o = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+        default: o = __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return v + __int_as_float(o);
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // lane ^ 16 inside each group of 32
+}
+
 // ---------------------------------------------------------------------------------------------
 // depthwise conv + LayerNorm  (CONV=false: LayerNorm only).  One wavefront per frame.
 // ---------------------------------------------------------------------------------------------
@@ -421,6 +439,309 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
     else
         STN_KLAUNCH((dwconv_ln_kernel<float, false>), grid, dim3(256), 0, s, x, M, 1, C, nullptr, nullptr, 1, 1, g, b,
                            eps, static_cast<float*>(y), static_cast<const int*>(nullptr));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Folding the pending update of a K4-split launch (kernels_ffn.hip) into the residual stream, inside the kernel that reads x
+// next anyway:   x_new = x + gamma * (((p0 + p1) + p2) + p3 + b2) + rowvec[seq]     (fp32, exactly this order in both kernels)
+// Everything a thread loads is loaded unconditionally and as whole vectors (a per-element "pointer ? load : constant" makes hipcc
+// branch around every load and wait for each one in turn: cdna_hip_programming.md, Projection GEMM item 4(c)); the optional
+// time vector is a template parameter, the split count a compile-time constant.
+// ---------------------------------------------------------------------------------------------
+static constexpr int FOLD_S = 4;  // splits a fold accepts (= ffn_split_factor of the estimator's block)
+template <bool F16>
+__device__ __forceinline__ float p16_to_f(unsigned h) {  // one 16-bit partial (low 16 bits of h) -> fp32
+    if constexpr (F16) { const _Float16 v = __builtin_bit_cast(_Float16, (uint16_t)h); return (float)v; }
+    else return __uint_as_float(h << 16);
+}
+// N consecutive channels of one row: w[sp][j] holds channels 2j, 2j+1 of split sp
+template <bool F16, int N>
+__device__ __forceinline__ void fold_sum(const unsigned (&w)[FOLD_S][N / 2], float (&acc)[N]) {
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) { acc[2 * j] = p16_to_f<F16>(w[0][j] & 0xFFFFu); acc[2 * j + 1] = p16_to_f<F16>(w[0][j] >> 16); }
+#pragma unroll
+    for (int sp = 1; sp < FOLD_S; ++sp)
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) { acc[2 * j] += p16_to_f<F16>(w[sp][j] & 0xFFFFu); acc[2 * j + 1] += p16_to_f<F16>(w[sp][j] >> 16); }
+}
+__device__ __forceinline__ float fold_one(float x, float y, float b2, float gm, float rv) { return x + gm * (y + b2) + rv; }
+__device__ __forceinline__ float4 fold_four(float4 x, const float* acc, float4 b2, float4 gm, float4 rv) {
+    return make_float4(fold_one(x.x, acc[0], b2.x, gm.x, rv.x), fold_one(x.y, acc[1], b2.y, gm.y, rv.y), fold_one(x.z, acc[2], b2.z, gm.z, rv.z),
+                       fold_one(x.w, acc[3], b2.w, gm.w, rv.w));
+}
+
+// fold + LayerNorm, one wavefront per row (rows are independent: x is updated in place)
+template <typename OutT, bool F16, bool RV>
+__global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ x, int64_t M, int C, const uint16_t* __restrict__ part,
+                                                      int64_t pstride, const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                      const float* __restrict__ rowvec, int rv_ld, const int* __restrict__ row_b,
+                                                      const float* __restrict__ g, const float* __restrict__ bt, float eps, OutT* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;  // wave-uniform
+    const int C4 = C >> 2;
+    float4* x4 = reinterpret_cast<float4*>(x) + row * C4;
+    const float4* rv4 = nullptr;
+    if constexpr (RV) rv4 = reinterpret_cast<const float4*>(rowvec + (size_t)(row_b ? row_b[row] : 0) * rv_ld);
+    const float4* b24 = reinterpret_cast<const float4*>(b2);
+    const float4* gm4 = reinterpret_cast<const float4*>(gamma);
+    float4 h[LN_NI];
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i) {
+        const int c4 = lane + 64 * i;
+        h[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < C4) {
+            const float4 xo = x4[c4];
+            unsigned w[FOLD_S][2];
+#pragma unroll
+            for (int sp = 0; sp < FOLD_S; ++sp) {
+                const uint2 u = *reinterpret_cast<const uint2*>(part + (size_t)sp * pstride + (size_t)row * C + c4 * 4);
+                w[sp][0] = u.x; w[sp][1] = u.y;
+            }
+            const float4 bb = b24[c4], gm = gm4[c4];
+            float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (RV) tv = rv4[c4];
+            float acc[4];
+            fold_sum<F16, 4>(w, acc);
+            h[i] = fold_four(xo, acc, bb, gm, tv);
+            x4[c4] = h[i];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i) s += (h[i].x + h[i].y) + (h[i].z + h[i].w);
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i)
+        if (lane + 64 * i < C4) {
+            const float dx = h[i].x - mean, dy = h[i].y - mean, dz = h[i].z - mean, dw = h[i].w - mean;
+            v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* bt4 = reinterpret_cast<const float4*>(bt);
+#pragma unroll
+    for (int i = 0; i < LN_NI; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < C4) {
+            const float4 gg = g4[c4], bb = bt4[c4];
+            store4(y + row * C + c4 * 4, (h[i].x - mean) * rstd * gg.x + bb.x, (h[i].y - mean) * rstd * gg.y + bb.y,
+                   (h[i].z - mean) * rstd * gg.z + bb.z, (h[i].w - mean) * rstd * gg.w + bb.w);
+        }
+    }
+}
+
+static void check_fold_args(const FoldArgs& f, int64_t M, int C, const char* who) {
+    if (!f.part || f.S != FOLD_S || f.part_stride < M * C || !f.b2 || !f.gamma || (f.rowvec && f.rv_ld % 4) || (reinterpret_cast<uintptr_t>(f.part) & 15) ||
+        (reinterpret_cast<uintptr_t>(f.b2) & 15) || (reinterpret_cast<uintptr_t>(f.gamma) & 15) || (f.rowvec && (reinterpret_cast<uintptr_t>(f.rowvec) & 15)))
+        throw std::invalid_argument(std::string(who) + ": needs 16-byte aligned partial sums of exactly 4 splits, b2 and gamma");
+}
+
+void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, const FoldArgs& f, const float* g, const float* b, float eps, void* y) {
+    check_ln_shape(C);
+    if (M == 0) return;
+    if (!is_half(act_dtype)) throw std::invalid_argument("launch_fold_ln: 16-bit activation format needed");
+    check_fold_args(f, M, C, "launch_fold_ln");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    const uint16_t* P = static_cast<const uint16_t*>(f.part);
+#define STN_FOLD_LN(OUT, F16_, RV_) STN_KLAUNCH((fold_ln_kernel<OUT, F16_, RV_>), grid, dim3(256), 0, s, x, M, C, P, f.part_stride, f.b2, f.gamma, f.rowvec, \
+                                                f.rv_ld, f.row_b, g, b, eps, static_cast<OUT*>(y))
+    if (act_dtype == F16) { if (f.rowvec) STN_FOLD_LN(f16_t, true, true); else STN_FOLD_LN(f16_t, true, false); }
+    else { if (f.rowvec) STN_FOLD_LN(uint16_t, false, true); else STN_FOLD_LN(uint16_t, false, false); }
+#undef STN_FOLD_LN
+}
+
+// fold + depthwise conv + LayerNorm on packed rows.  A workgroup (16 wavefronts) owns a run of consecutive frames of ONE sequence
+// (a sequence is cut into ceil(len / 32) runs of equal length): it folds those frames and the (K-1)/2 * dil halo frames on either
+// side into an fp32 LDS image (phase 1), runs the conv + LayerNorm out of LDS, one frame per half wavefront (phase 2), and writes
+// the folded frames it owns to x_out.  x_out != x_in: the halo frames are folded again by the neighbouring workgroup from the
+// same inputs.
+// The kernel is a chain of memory latencies, not of bytes (one workgroup per CU, ~150 KB each): everything is arranged so that
+// the chain is ONE global round trip long — the conv / LayerNorm parameters ride to LDS beside the phase-1 loads (no global load
+// behind the barrier), nothing is stored to global memory before the barrier (a store in flight would be waited for there), and
+// the x_out stores are the last thing a thread issues.
+static constexpr int FOLD_TCH = 32, FOLD_NT = 1024;  // FOLD_TCH == 2 * wavefronts per workgroup
+template <typename OutT, bool F16, int K, bool RV, int FOLD_NSLOT /* float4 slots per lane of a half wavefront: ceil(C / 128) */>
+__global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __restrict__ xin, float* __restrict__ xout, int cps, int C,
+                                                                 const uint16_t* __restrict__ part, int64_t pstride,
+                                                                 const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ rowvec, int rv_ld, const float* __restrict__ w_t,
+                                                                 const float* __restrict__ bias, int dil, const float* __restrict__ g,
+                                                                 const float* __restrict__ bt, float eps, OutT* __restrict__ y,
+                                                                 const int* __restrict__ seqlen, const int* __restrict__ row_off,
+                                                                 unsigned long long* __restrict__ ts) {
+    extern __shared__ __attribute__((aligned(16))) float fold_sm[];
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (ts) st0 = __builtin_readcyclecounter();
+    const int b = (int)blockIdx.x / cps, c = (int)blockIdx.x % cps;
+    const int Lv = seqlen[b];
+    const int64_t row0 = (int64_t)row_off[b];
+    const int nch = (Lv + FOLD_TCH - 1) / FOLD_TCH;
+    if (c >= nch) return;
+    const int per = (Lv + nch - 1) / nch;
+    const int t0 = c * per, t1 = min(t0 + per, Lv);
+    if (t0 >= t1) return;
+    constexpr int HALF = (K - 1) / 2;
+    const int w0 = max(t0 - HALF * dil, 0), w1 = min(t1 + HALF * dil, Lv), nw = w1 - w0;
+    const int tid = threadIdx.x, C8 = C >> 3, C4 = C >> 2;
+    // the parameters of phase 2 as one LDS block behind the image: [K taps][C] | conv bias | LayerNorm g | LayerNorm b
+    float* const wsm = fold_sm + (size_t)(FOLD_TCH + (K - 1) * dil) * C;
+    constexpr int NPV = (K + 3 + 7) / 8;  // float4 per thread: (K + 3) * C4 <= NPV * FOLD_NT for C <= 512, K <= 7 ... checked by the launcher
+    float4 pv[NPV];
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+        const int q = tid + i * FOLD_NT;  // float4 index into the block
+        const int seg = q / C4, c4 = q - seg * C4;
+        const float* src = seg < K ? w_t + (size_t)seg * C : seg == K ? bias : seg == K + 1 ? g : bt;
+        pv[i] = q < (K + 3) * C4 ? reinterpret_cast<const float4*>(src)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- phase 1: a thread keeps ONE 8-channel group (its b2 / gamma / time-vector values are loaded once) and walks down the
+    // window rows, `rpp` rows apart; every load of U rows is issued before the first use ----
+    constexpr int U = 2;
+    const int rpp = FOLD_NT / C8;  // rows per pass of the workgroup
+    const int c8 = tid % C8, rq = tid / C8;
+    if (rq < rpp) {
+        const float4* bp = reinterpret_cast<const float4*>(b2 + c8 * 8);
+        const float4* gp = reinterpret_cast<const float4*>(gamma + c8 * 8);
+        const float4 bb0 = bp[0], bb1 = bp[1], gm0 = gp[0], gm1 = gp[1];
+        float4 tv0 = make_float4(0.f, 0.f, 0.f, 0.f), tv1 = tv0;
+        if constexpr (RV) { const float4* tp = reinterpret_cast<const float4*>(rowvec + (size_t)b * rv_ld + c8 * 8); tv0 = tp[0]; tv1 = tp[1]; }
+        for (int r0 = rq; r0 < nw; r0 += rpp * U) {
+            float4 xa[U][2];
+            unsigned w[U][FOLD_S][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = min(r0 + u * rpp, nw - 1);  // (past the end: the last row again, stored nowhere)
+                const int64_t m = row0 + w0 + r;
+                const float4* xp = reinterpret_cast<const float4*>(xin + m * C + c8 * 8);
+                xa[u][0] = xp[0]; xa[u][1] = xp[1];
+#pragma unroll
+                for (int sp = 0; sp < FOLD_S; ++sp) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(part + (size_t)sp * pstride + (size_t)m * C + c8 * 8);
+                    w[u][sp][0] = q.x; w[u][sp][1] = q.y; w[u][sp][2] = q.z; w[u][sp][3] = q.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float acc[8];
+                fold_sum<F16, 8>(w[u], acc);
+                const int r = r0 + u * rpp;
+                if (r < nw) {
+                    float4* sp4 = reinterpret_cast<float4*>(fold_sm + (size_t)r * C + c8 * 8);
+                    sp4[0] = fold_four(xa[u][0], acc, bb0, gm0, tv0);
+                    sp4[1] = fold_four(xa[u][1], acc + 4, bb1, gm1, tv1);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+        const int q = tid + i * FOLD_NT;
+        if (q < (K + 3) * C4) reinterpret_cast<float4*>(wsm)[q] = pv[i];
+    }
+    if (ts) st1 = __builtin_readcyclecounter();
+    __syncthreads();
+    if (ts) st2 = __builtin_readcyclecounter();
+    // ---- phase 2: one frame per HALF wavefront (32 lanes x FOLD_NSLOT float4 slots cover C): all of a run's <= 32 frames are done
+    // in one pass of the 16 wavefronts, and the two LayerNorm reductions are 4 DPP steps + one swizzle over 32 lanes ----
+    const int lane = tid & 63, l32 = lane & 31;
+    const int t = t0 + 2 * (tid >> 6) + (lane >> 5);
+    const bool live = t < t1;
+    const int tl = live ? t : t0;  // (a half wavefront beyond the run computes frame t0 again and stores nothing)
+    const float4* ws4 = reinterpret_cast<const float4*>(wsm);
+    float4 h[FOLD_NSLOT];
+#pragma unroll
+    for (int i = 0; i < FOLD_NSLOT; ++i) {
+        const int c4 = l32 + 32 * i, cq = c4 < C4 ? c4 : 0;
+        float4 a = ws4[K * C4 + cq];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int tt = tl + (j - HALF) * dil;
+            const bool in = tt >= 0 && tt < Lv;  // (then w0 <= tt < w1)
+            const float4 xv = *reinterpret_cast<const float4*>(fold_sm + (size_t)((in ? tt : tl) - w0) * C + cq * 4);
+            const float4 wv = ws4[j * C4 + cq];
+            const float keep = in ? 1.f : 0.f;
+            a.x = fmaf(wv.x * keep, xv.x, a.x); a.y = fmaf(wv.y * keep, xv.y, a.y);
+            a.z = fmaf(wv.z * keep, xv.z, a.z); a.w = fmaf(wv.w * keep, xv.w, a.w);
+        }
+        h[i] = c4 < C4 ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < FOLD_NSLOT; ++i) s += (h[i].x + h[i].y) + (h[i].z + h[i].w);
+    const float mean = half_wave_sum(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < FOLD_NSLOT; ++i)
+        if (l32 + 32 * i < C4) {
+            const float dx = h[i].x - mean, dy = h[i].y - mean, dz = h[i].z - mean, dw = h[i].w - mean;
+            v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    const float rstd = rsqrtf(half_wave_sum(v) / (float)C + eps);
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < FOLD_NSLOT; ++i) {
+            const int c4 = l32 + 32 * i;
+            if (c4 < C4) {
+                const float4 gg = ws4[(K + 1) * C4 + c4], bb = ws4[(K + 2) * C4 + c4];
+                store4(y + (row0 + t) * C + c4 * 4, (h[i].x - mean) * rstd * gg.x + bb.x, (h[i].y - mean) * rstd * gg.y + bb.y,
+                       (h[i].z - mean) * rstd * gg.z + bb.z, (h[i].w - mean) * rstd * gg.w + bb.w);
+            }
+        }
+    }
+    // ---- the folded frames this run owns -> x_out (each thread: the image rows it wrote itself) ----
+    if (rq < rpp)
+        for (int r = rq; r < nw; r += rpp) {
+            const int tt = w0 + r;
+            if (tt >= t0 && tt < t1) {
+                const float4* sp4 = reinterpret_cast<const float4*>(fold_sm + (size_t)r * C + c8 * 8);
+                float4* op = reinterpret_cast<float4*>(xout + (row0 + tt) * C + c8 * 8);
+                op[0] = sp4[0]; op[1] = sp4[1];
+            }
+        }
+    if (ts && tid == 0) {
+        unsigned long long* tp = ts + (size_t)blockIdx.x * 4;
+        tp[0] = st0; tp[1] = st1; tp[2] = st2; tp[3] = __builtin_readcyclecounter();
+    }
+}
+
+static size_t fold_dwconv_lds(int C, int k, int dil) { return ((size_t)(FOLD_TCH + (k - 1) * dil) + (size_t)(k + 3)) * C * 4; }  // image + parameter block
+bool fold_dwconv_ln_supported(int C, int k, int dil) {
+    return C % 8 == 0 && C <= 512 && (k == 5 || k == 7) && dil >= 1 && fold_dwconv_lds(C, k, dil) <= 160 * 1024;
+}
+
+template <typename OutT, bool F16, int K, bool RV, int NSLOT>
+static void launch_fold_dwconv_ln_t2(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
+                                     const float* bias, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen, const int* row_off) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need())
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024), "hipFuncSetAttribute(fold_dwconv_ln)");
+    const int cps = (L + FOLD_TCH - 1) / FOLD_TCH;
+    STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil), s, x_in, x_out, cps, C,
+                static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, y, seqlen, row_off, f.ts);
+}
+template <typename OutT, bool F16, int K, bool RV>
+static void launch_fold_dwconv_ln_t(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
+                                    const float* bias, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen, const int* row_off) {
+    if (C <= 384) launch_fold_dwconv_ln_t2<OutT, F16, K, RV, 3>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+    else launch_fold_dwconv_ln_t2<OutT, F16, K, RV, 4>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+}
+
+void launch_fold_dwconv_ln(hipStream_t s, int act_dtype, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
+                           const float* bias, int k, int dil, const float* ln_g, const float* ln_b, float eps, void* y, const int* seqlen,
+                           const int* row_off) {
+    if (B == 0 || L == 0) return;
+    if (!is_half(act_dtype) || !seqlen || !row_off || x_in == x_out || !fold_dwconv_ln_supported(C, k, dil) ||
+        (int64_t)B * ((L + FOLD_TCH - 1) / FOLD_TCH) > 0x7FFFFFFFll)
+        throw std::invalid_argument("launch_fold_dwconv_ln: packed 16-bit rows, separate output, k in {5,7}, C % 8 == 0, C <= 512 needed");
+    check_fold_args(f, 0, C, "launch_fold_dwconv_ln");
+#define STN_FOLD_DW(OUT, F16_, K_) do { if (f.rowvec) launch_fold_dwconv_ln_t<OUT, F16_, K_, true>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, ln_g, ln_b, eps, static_cast<OUT*>(y), seqlen, row_off); \
+                                        else launch_fold_dwconv_ln_t<OUT, F16_, K_, false>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, ln_g, ln_b, eps, static_cast<OUT*>(y), seqlen, row_off); } while (0)
+    if (act_dtype == F16) { if (k == 5) STN_FOLD_DW(f16_t, true, 5); else STN_FOLD_DW(f16_t, true, 7); }
+    else { if (k == 5) STN_FOLD_DW(uint16_t, false, 5); else STN_FOLD_DW(uint16_t, false, 7); }
+#undef STN_FOLD_DW
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -21,6 +21,11 @@ def test_bench_json_line_contract():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == int(os.environ.get("WORLD_SIZE", "1"))
+    # the timed region is the production path: hipGraph replays of the post-duration pipeline, exactly K of them; the event-timed
+    # (eager) pass that feeds `roofline` is a separate K steps printed beside it
+    assert d["graph_replays_in_timed_region"] == d["steps"] and d["config"]["warmup_steps_run"] >= 3
+    assert d["eager_sampled"]["ms_per_step"] > 0 and d["eager_sampled"]["ms_per_step"] > 0.9 * d["ms_per_step"]
     assert d["vs_baseline"] is None and d["unit"] == "audio-sec/sec" and d["dtype"] == "bf16" and "synthetic" in d["data"]
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1000 and abs(d["value"] - d["config"]["audio_sec_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
@@ -59,3 +64,27 @@ def test_bench_strong_scaling_flag():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["global_batch"] == 128 and d["config"]["batch_per_gpu"] == 128
+
+
+def test_bench_multi_gpu_code_path_at_world_1():
+    """STN_BENCH_FORCE_DIST=1: the N > 1 code path on the one GPU a test box has — `nccl` process group (RCCL), the engine on the shared
+    torch stream, GatherPlan, the int16 PCM gather overlapped with the next step — and what rank 0 gathered equals stn_batch_fetch_pcm16."""
+    env = dict(os.environ, STN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-host-loop", "--no-b1",
+                        "--no-profile"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    g = d["gather_check"]
+    assert g["equal_rank0_block"] and g["durations_equal"] and g["crc32_gathered"] == g["crc32_fetch_pcm16"]
+    assert g["blocks"] == [[128, g["blocks"][0][1]]] and all(g["nonzero_blocks"]) and g["bytes_per_gather"] > 10e6
+    assert d["n_gpus"] == 1 and d["graph_replays_in_timed_region"] == 2 and d["value"] > 1000
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import torch
+    n = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert p.returncode != 0 and "visible" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -144,3 +144,109 @@ def test_ffn_f16_rows_do_not_depend_on_position(eng16):
     sel = np.r_[3:40, 129:300, 511:700]
     part = eng16.op_ffn(ops[0][sel], *ops[1:6], ops[6][sel], fused=True)
     assert np.array_equal(full[sel], part)
+
+
+# ---- K4-split: the hidden dimension cut over four workgroups per slab, 16-bit partial sums, folded by the next reader of x ----------
+
+def ref64_split(xn, W1, b1, W2, b2, gamma, x, rowvec, row_b, S=4, rnd=bf16_round):
+    """float64 restatement with the kernel's rounding points: xn, weights and the GELU'd hidden activation in the 16-bit format, each
+    hidden quarter's contribution rounded to 16 bits, then the fold in fp32 in the kernels' order."""
+    h = rnd(xn).astype(np.float64) @ rnd(W1).astype(np.float64).T + b1
+    g = rnd(gelu(h).astype(np.float32)).astype(np.float64)
+    I = W1.shape[0]
+    q = I // S
+    w2 = rnd(W2).astype(np.float64)
+    parts = [rnd((g[:, s * q:(s + 1) * q] @ w2[:, s * q:(s + 1) * q].T).astype(np.float32)) for s in range(S)]
+    y = parts[0]
+    for p in parts[1:]:
+        y = (y + p).astype(np.float32)
+    out = (x + gamma * (y + b2).astype(np.float32)).astype(np.float32)
+    if rowvec is not None:
+        out = out + rowvec[row_b]
+    return out
+
+
+@pytest.mark.parametrize("M,nseq", [(7436, 128), (1000, 0), (129, 0), (31, 3)])
+def test_ffn_split_vs_float64_and_two_launches(eng, M, nseq):
+    C, I = 384, 1536
+    ops = make(M, C, I, 7 * M + 1, nseq)
+    got = eng.op_ffn(*ops[:7], rowvec=ops[7], row_b=ops[8], fused=2)
+    assert np.all(np.isfinite(got))
+    x = ops[6]
+    mx, rms = rel_err(got - x, ref64_split(*ops) - x)
+    assert rms < 3e-3 and mx < 3e-2, (mx, rms)
+    # against the unsplit float64 reference and the two launches: the 16-bit partial sums add ~2^-9 of a quarter's contribution
+    mx, rms = rel_err(got - x, ref64(*ops) - x)
+    assert rms < 6e-3 and mx < 5e-2, (mx, rms)
+    two = eng.op_ffn(*ops[:7], rowvec=ops[7], row_b=ops[8], fused=0)
+    mx, rms = rel_err(got - x, two - x)
+    assert rms < 6e-3 and mx < 5e-2, (mx, rms)
+
+
+def test_ffn_split_rows_do_not_depend_on_position_or_row_count(eng):
+    """The split is a function of the block's shape only: a row gives the same bits alone, in another slab, in another launch size."""
+    M, C, I = 700, 384, 1536
+    ops = make(M, C, I, 9)
+    full = eng.op_ffn(*ops[:7], fused=2)
+    sel = np.r_[3:40, 129:300, 511:700]
+    part = eng.op_ffn(ops[0][sel], *ops[1:6], ops[6][sel], fused=2)
+    assert np.array_equal(full[sel], part)
+    one = eng.op_ffn(ops[0][5:6], *ops[1:6], ops[6][5:6], fused=2)
+    assert np.array_equal(full[5:6], one)
+
+
+def test_ffn_split_f16(eng16):
+    M, C, I = 1500, 384, 1536
+    ops = make(M, C, I, 77, 16)
+    got = eng16.op_ffn(*ops[:7], rowvec=ops[7], row_b=ops[8], fused=2)
+    x = ops[6]
+    mx, rms = rel_err(got - x, ref64_split(*ops, rnd=f16_round) - x)
+    assert rms < 1.5e-3 and mx < 1.5e-2 and np.all(np.isfinite(got)), (mx, rms)
+
+
+def _fold_dwconv_ref(seqlen, x, part16, b2, gamma, rowvec, w, bias, g, b, k, dil, eps=1e-6):
+    S, M, C = part16.shape
+    y = part16[0]
+    for s in range(1, S):
+        y = (y + part16[s]).astype(np.float32)
+    off = np.r_[0, np.cumsum(seqlen)]
+    seq = np.repeat(np.arange(len(seqlen)), seqlen)
+    xo = (x + gamma * (y + b2).astype(np.float32)).astype(np.float32)
+    if rowvec is not None:
+        xo = (xo + rowvec[seq]).astype(np.float32)
+    out = np.zeros((M, C), np.float64)
+    half = (k - 1) // 2
+    for bi, n in enumerate(seqlen):
+        xs = xo[off[bi]:off[bi] + n].astype(np.float64)
+        acc = np.tile(bias.astype(np.float64), (n, 1))
+        for j in range(k):
+            sh = (j - half) * dil
+            lo, hi = max(0, -sh), min(n, n - sh)
+            if hi > lo:
+                acc[lo:hi] += w[:, j] * xs[lo + sh:hi + sh]
+        mu = acc.mean(1, keepdims=True)
+        var = ((acc - mu) ** 2).mean(1, keepdims=True)
+        out[off[bi]:off[bi] + n] = (acc - mu) / np.sqrt(var + eps) * g + b
+    return xo, out
+
+
+@pytest.mark.parametrize("k,dil,C", [(5, 1, 384), (5, 2, 384), (5, 4, 384), (5, 8, 384), (7, 2, 512), (5, 8, 96)])
+def test_fold_dwconv_ln_vs_numpy(eng, k, dil, C):
+    rng = np.random.default_rng(100 * k + dil + C)
+    seqlen = np.array([1, 5, 33, 64, 70, 150, 2, 31, 32, 96, 97], np.int32)
+    M, S = int(seqlen.sum()), 4
+    x = rng.standard_normal((M, C)).astype(np.float32)
+    part = bf16_round((0.5 * rng.standard_normal((S, M, C))).astype(np.float32))
+    b2 = (0.3 * rng.standard_normal(C)).astype(np.float32)
+    gamma = (0.5 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    rowvec = rng.standard_normal((len(seqlen), C)).astype(np.float32)
+    w = (rng.standard_normal((C, k)) / np.sqrt(k)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    for rv in (rowvec, None):
+        xo, y = eng.op_fold_dwconv_ln(seqlen, x, part, b2, gamma, rv, w, bias, g, b, k, dil)
+        rxo, ry = _fold_dwconv_ref(seqlen, x, part, b2, gamma, rv, w, bias, g, b, k, dil)
+        assert np.array_equal(xo, rxo)  # the fold is elementwise fp32 in a fixed order: exact
+        mx, rms = rel_err(y, ry)
+        assert rms < 4e-3 and mx < 4e-2, (mx, rms)  # one bf16 rounding of the normalised output (2^-9 of values up to ~5 sigma)
