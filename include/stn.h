@@ -236,6 +236,13 @@ int stn_op_randn(stn_handle* h, uint64_t seed, int B, int D, int L, const int64_
                  const int32_t* len_or_null, float* out);
 
 const char* stn_version(void);
+/* HIP runtime versions: the one libstn.so was compiled against and the one it runs on (they differ when the process loaded
+ * PyTorch-ROCm's bundled runtime first); no device needed */
+int stn_hip_versions(int* built, int* runtime);
+/* forms of the pointwise pair the kernels offer for a block shape (no device needed): 0 = two tiled launches only, 1 = K4,
+ * 2 = K4 and K4-split.  Counts the LDS a workgroup needs (ring + biases <= 160 KiB), so a descriptor that loads never selects a
+ * kernel that cannot launch. */
+int stn_ffn_fused_forms(int dtype, int C, int I);
 
 #ifdef __cplusplus
 }

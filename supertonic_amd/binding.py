@@ -32,6 +32,29 @@ _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 
 
+def runtime_info(L=None):
+    """{'hip_built': ..., 'hip_runtime': ..., 'torch_preloaded': ...}: which HIP runtime libstn.so was compiled against and which
+    one this process bound it to (PyTorch-ROCm wheels bundle their own; importing torch first makes that the one in use)."""
+    import sys
+    L = L or load()
+    b, r = ctypes.c_int(), ctypes.c_int()
+    L.stn_hip_versions(ctypes.byref(b), ctypes.byref(r))
+    return {"hip_built": b.value, "hip_runtime": r.value, "torch_preloaded": "torch" in sys.modules, "lib": LIB_PATH}
+
+
+def _check_runtime(L):
+    """libstn.so's code objects are built and tested with the system ROCm; when the process bound it to another HIP runtime major.minor
+    (torch's bundled copy), say so once: not an error — the GPU suite runs in exactly that configuration and
+    records it (tests/test_gpu_runtime_record.py) — but a mismatch the user should be able to see."""
+    import warnings
+    info = runtime_info(L)
+    b, r = info["hip_built"], info["hip_runtime"]
+    if r > 0 and (b // 100000) != (r // 100000):  # HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+        warnings.warn(f"libstn.so was built against HIP {b // 10000000}.{b // 100000 % 100} but runs on HIP runtime {r // 10000000}.{r // 100000 % 100}"
+                      + (" (PyTorch's bundled runtime was loaded first; set STN_NO_TORCH_PRELOAD=1 in processes that do not need torch)" if info["torch_preloaded"] else ""),
+                      RuntimeWarning, stacklevel=3)
+
+
 def load():
     """Load libstn.so (built by `make` / __graft_entry__.build()).  Raises if it is not there."""
     global _LIB
@@ -51,6 +74,9 @@ def load():
             import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cu64, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
+    L.stn_hip_versions.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.stn_ffn_fused_forms.argtypes = [ci, ci, ci]
+    _check_runtime(L)
     L.stn_version.restype = ctypes.c_char_p
     L.stn_create.argtypes = [ctypes.POINTER(StnConfig), ctypes.POINTER(vp)]
     L.stn_destroy.argtypes = [vp]

@@ -49,6 +49,21 @@ extern "C" {
 
 const char* stn_version(void) { return "supertonic_amd 0.1 (gfx950)"; }
 
+/* HIP runtime the library was compiled against vs the one it is running on (a process that imports PyTorch first binds libstn.so
+ * to the runtime bundled with the wheel): for the record, and for a warning in the Python binding when they differ */
+int stn_hip_versions(int* built, int* runtime) {
+    int rt = 0;
+    const hipError_t e = hipRuntimeGetVersion(&rt);
+    if (built) *built = HIP_VERSION;
+    if (runtime) *runtime = e == hipSuccess ? rt : -1;
+    return e == hipSuccess ? STN_OK : STN_ERR_DEVICE;
+}
+/* which form of the pointwise pair the kernels offer for a block shape: 0 = two tiled launches only, 1 = K4, 2 = K4 and K4-split */
+int stn_ffn_fused_forms(int dtype, int C, int I) {
+    if (C <= 0 || I <= 0 || !stn::ffn_fused_supported(dtype, C, I)) return 0;
+    return stn::ffn_split_factor(dtype, C, I) > 1 ? 2 : 1;
+}
+
 int stn_create(const stn_config* cfg, stn_handle** out) {
     if (!cfg || !out) { g_create_err = "stn_create: null argument"; return STN_ERR_INVALID; }
     *out = nullptr;
@@ -126,9 +141,10 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
         stn::graphbind::check_all_io_names(models.at(graphs[0]), models.at(graphs[1]), models.at(graphs[2]), models.at(graphs[3]));
         {
             std::ifstream probe(man_path);
-            if (!probe.is_open()) {
-                // no manifest: recognise the layout in the graphs themselves (host/graph_bind.hpp)
-                const stn::graphbind::Result gb = stn::graphbind::bind(a, models.at(graphs[0]), models.at(graphs[1]), models.at(graphs[2]), models.at(graphs[3]));
+            const bool heads_explicit = probe.is_open() && stn::graphbind::apply_arch_overrides(dir, a);  // a manifest without "tensors": head counts only
+            if (!probe.is_open() || heads_explicit) {
+                // no tensor table: recognise the layout in the graphs themselves (host/graph_bind.hpp)
+                const stn::graphbind::Result gb = stn::graphbind::bind(a, models.at(graphs[0]), models.at(graphs[1]), models.at(graphs[2]), models.at(graphs[3]), heads_explicit);
                 h->eng->load_tensors(gb.arch, [&](const std::string& name, int rows, int cols) {
                     auto it = gb.tensors.find(name);
                     if (it == gb.tensors.end()) throw std::runtime_error("graph binding: no initializer was bound to tensor \"" + name + "\"");

@@ -35,6 +35,8 @@ struct Tok {
     int out = 0, in = 0, k = 1, dil = 1;
     bool transposed = false;      // LINEAR stored [in][out]
     int heads = 0;                // head count of the first 4-D Reshape constant between this token and the next one
+    std::string out_name;         // SCALE: the value it produces (a decomposed LayerNorm's beta Add refers to it)
+    bool norm_scale = false;      // SCALE whose input is a normalised value (x - mean) / sqrt(var + eps): the gamma of a decomposed LayerNorm
 };
 
 std::string dims_str(const Tensor* t) {
@@ -53,9 +55,13 @@ std::vector<int64_t> squeezed(const Tensor* t) {
     return d;
 }
 
-std::vector<Tok> weighted_nodes(const Model& m, const std::string& file) {
+std::vector<Tok> weighted_nodes(const Model& m, const std::string& file, std::string* gelu_form = nullptr) {
     std::unordered_map<std::string, const Tensor*> init;
     for (const Tensor& t : m.initializers) init[t.name] = &t;
+    std::unordered_map<std::string, std::string> made_by;  // value name -> operator that produced it
+    for (const Node& n : m.nodes) for (const std::string& o : n.outputs) made_by[o] = n.op_type;
+    auto from_op = [&](const std::string& v) -> const std::string& { static const std::string none; auto it = made_by.find(v); return it == made_by.end() ? none : it->second; };
+    std::unordered_map<std::string, int> scale_tok;  // value name -> index of the SCALE token that produced it
     auto get = [&](const Node& n, size_t i) -> const Tensor* {
         if (i >= n.inputs.size()) return nullptr;
         auto it = init.find(n.inputs[i]);
@@ -69,6 +75,11 @@ std::vector<Tok> weighted_nodes(const Model& m, const std::string& file) {
         t.node = (int)ni;
         t.where = file + ": node #" + std::to_string(ni) + " " + n.op_type + " '" + n.name + "'";
         bool emit = false;
+        if (gelu_form) {  // how the graph writes the activation (Result::gelu)
+            if (n.op_type == "Gelu") { if (gelu_form->empty()) *gelu_form = n.attr_s("approximate", "none") == "tanh" ? "tanh" : "op"; }
+            else if (n.op_type == "Erf") *gelu_form = "erf";
+            else if (n.op_type == "Tanh" && *gelu_form != "erf") *gelu_form = "tanh";
+        }
         if (n.op_type == "Gather") {
             const Tensor* w = get(n, 0);
             if (is_float(w) && w->dims.size() == 2) { t.kind = EMBED; t.w = w; t.out = (int)w->dims[0]; t.in = (int)w->dims[1]; emit = true; }
@@ -111,11 +122,27 @@ std::vector<Tok> weighted_nodes(const Model& m, const std::string& file) {
                         if (!n.outputs.empty()) producer[n.outputs[0]] = p->second;
                         continue;
                     }
+                    // decomposed LayerNorm: ... Div -> Mul gamma -> Add beta.  The Mul was recorded as a normalising scale; this Add
+                    // completes it into a LayerNorm token
+                    auto sc = scale_tok.find(other);
+                    if (sc != scale_tok.end() && toks[sc->second].norm_scale && toks[sc->second].kind == SCALE && toks[sc->second].out == (int)c->numel() &&
+                        squeezed(c).size() <= 1) {
+                        Tok& g = toks[sc->second];
+                        g.kind = LN; g.b = c;
+                        g.where += " + node #" + std::to_string(ni) + " Add (decomposed LayerNormalization)";
+                        continue;
+                    }
                 }
                 if (c->numel() > 1) {  // scalars (attention scale, epsilons) are not weights
                     if (squeezed(c).size() != 1) { t.kind = OTHER; t.w = c; emit = true; }
                     else if (n.op_type == "Add") { t.kind = OTHER; t.w = c; emit = true; t.where += " (a constant vector added to something that is not a bias-free projection of that width)"; }
-                    else { t.kind = SCALE; t.w = c; t.out = t.in = (int)c->numel(); emit = true; }
+                    else {
+                        t.kind = SCALE; t.w = c; t.out = t.in = (int)c->numel(); emit = true;
+                        // (x - mean) / sqrt(var + eps) arrives from a Div, or from a Mul by a Reciprocal / Rsqrt-style value
+                        const std::string& src = from_op(other);
+                        t.norm_scale = src == "Div" || src == "InstanceNormalization" || src == "MeanVarianceNormalization";
+                        if (!n.outputs.empty()) t.out_name = n.outputs[0];
+                    }
                 }
             }
         } else if (n.op_type == "Reshape") {
@@ -132,8 +159,12 @@ std::vector<Tok> weighted_nodes(const Model& m, const std::string& file) {
         }
         if (!emit) continue;
         if (t.kind == LINEAR && !n.outputs.empty()) producer[n.outputs[0]] = (int)toks.size();
+        if (t.kind == SCALE && !t.out_name.empty()) scale_tok[t.out_name] = (int)toks.size();
         toks.push_back(t);
     }
+    // a normalising scale that no beta followed is a LayerNorm without bias (beta = zeros)
+    for (Tok& t : toks)
+        if (t.kind == SCALE && t.norm_scale) { t.kind = LN; t.where += " (decomposed LayerNormalization without beta)"; }
     return toks;
 }
 
@@ -173,10 +204,11 @@ struct Parser {
         o << ". Derived so far: " << arch_so_far(r.arch, stage);
         throw std::runtime_error(o.str());
     }
-    void bind(const std::string& name, const Tensor* ten, bool transpose, const Tok& tok) {
+    void bind(const std::string& name, const Tensor* ten, bool transpose, const Tok& tok, int row0 = 0, int rows_total = 0) {
         Bound b;
-        b.t = ten; b.transpose = transpose;
+        b.t = ten; b.transpose = transpose; b.row0 = row0; b.rows_total = rows_total;
         b.from = tok.where + (ten ? " initializer '" + ten->name + "' " + dims_str(ten) : " (no such input: zeros)");
+        if (rows_total) b.from += " rows " + std::to_string(row0) + ".. of " + std::to_string(rows_total);
         r.tensors[name] = b;
     }
     static std::string shape(int out, int in) { return (out < 0 ? std::string("?") : std::to_string(out)) + " <- " + (in < 0 ? std::string("?") : std::to_string(in)); }
@@ -218,15 +250,40 @@ struct Parser {
         return dil;
     }
     // attention block: LayerNorm -> q, k, v projections -> (attention) -> output projection.  cctx < 0: from the graph.  Returns heads (0 = not in the graph).
+    // Fused forms: ONE projection of 3c rows from the block's own input (q | k | v, self-attention) or q alone followed by ONE
+    // projection of 2c rows from the context (k | v): their row blocks are bound as the separate canonical tensors.
     int attn(const std::string& name, int c, int& cctx) {
         ln(name + ".ln", c);
         int heads = 0;
         auto h = [&](const Tok& tk) { if (!heads) heads = tk.heads; };
-        h(linear(name + ".q", c, c));
-        const Tok& kk = linear(name + ".k", c, cctx);
-        cctx = kk.in;
-        h(kk);
-        h(linear(name + ".v", c, cctx));
+        auto fused = [&](const Tok& tk, std::initializer_list<const char*> parts) {
+            const int n = (int)parts.size();
+            int j = 0;
+            for (const char* part : parts) {
+                bind(name + "." + part + ".w", tk.w, tk.transposed, tk, j * c, n * c);
+                bind(name + "." + part + ".b", tk.b, false, tk, j * c, tk.b ? n * c : 0);
+                ++j;
+            }
+            h(tk);
+            ++i;
+        };
+        const Tok* p = peek();
+        if (p && p->kind == LINEAR && p->out == 3 * c && p->in == c && (cctx < 0 || cctx == c)) {
+            cctx = c;
+            fused(*p, {"q", "k", "v"});
+        } else {
+            h(linear(name + ".q", c, c));
+            p = peek();
+            if (p && p->kind == LINEAR && p->out == 2 * c && (cctx < 0 || p->in == cctx)) {
+                cctx = p->in;
+                fused(*p, {"k", "v"});
+            } else {
+                const Tok& kk = linear(name + ".k", c, cctx);
+                cctx = kk.in;
+                h(kk);
+                h(linear(name + ".v", c, cctx));
+            }
+        }
         linear(name + ".o", c, c);
         return heads;
     }
@@ -235,11 +292,19 @@ struct Parser {
     }
 };
 
-void set_heads(Result& r, int32_t& field, const char* fname, int found, int c) {
+void set_heads(Result& r, int32_t& field, const char* fname, int found, int c, bool explicit_) {
     if (found > 0) {
         if (c % found) throw std::runtime_error(std::string(fname) + " = " + std::to_string(found) + " (from a Reshape constant) does not divide the width " + std::to_string(c));
         field = found;
-    } else r.notes += std::string(fname) + " is not readable from the graph (no [batch, length, heads, head_dim] Reshape constant inside the block): kept at " + std::to_string(field) + "; ";
+        return;
+    }
+    // A head count changes every attention result and no weight shape shows it: never guessed.
+    if (!explicit_)
+        throw std::runtime_error(std::string(fname) + " is not readable from the graph (no [batch, length, heads, head_dim] Reshape constant inside an attention block) "
+                                 "and was not stated: put {\"arch\": {\"" + fname + "\": <n>}} into stn_weight_map.json beside the graphs (a manifest without a "
+                                 "\"tensors\" table only states descriptor fields; the graphs are still walked)");
+    if (field <= 0 || c % field) throw std::runtime_error(std::string(fname) + " = " + std::to_string(field) + " (stated in stn_weight_map.json) does not divide the width " + std::to_string(c));
+    r.notes += std::string(fname) + " = " + std::to_string(field) + " as stated in stn_weight_map.json (the graph does not carry it); ";
 }
 void agree(const char* what, int from_graph, int from_json, const std::string& file) {
     if (from_graph != from_json)
@@ -248,7 +313,7 @@ void agree(const char* what, int from_graph, int from_json, const std::string& f
 
 }  // namespace
 
-Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Model& vem, const Model& vom) {
+Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Model& vem, const Model& vom, bool heads_explicit) {
     Result r;
     r.arch = base;
     stn_arch& a = r.arch;
@@ -256,7 +321,9 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
     const int D = base.latent_dim * base.chunk_compress_factor;
 
     {   // ---- duration predictor: embedding, ConvNeXt x n, style cross-attention, LayerNorm, two projections -------------------
-        const std::vector<Tok> toks = weighted_nodes(dpm, "duration_predictor.onnx");
+        std::string gelu;
+        const std::vector<Tok> toks = weighted_nodes(dpm, "duration_predictor.onnx", &gelu);
+        r.gelu = gelu;
         Parser p{toks, "duration_predictor.onnx", "dp", r};
         a.dp_conv_blocks = 0;
         const Tok* e = p.peek();
@@ -267,7 +334,7 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
         int c = a.dp_dim, hid = -1, k = -1;
         while (p.next_is(DWCONV)) { p.convnext(S("dp.conv%d", a.dp_conv_blocks), c, hid, k, 1); ++a.dp_conv_blocks; a.dp_hidden = hid; a.dp_kernel = k; }
         int cctx = -1;
-        set_heads(r, a.dp_heads, "dp_heads", p.attn("dp.st", c, cctx), c);
+        set_heads(r, a.dp_heads, "dp_heads", p.attn("dp.st", c, cctx), c, heads_explicit);
         agree("d_style_dp (key projection of dp.st)", cctx, base.d_style_dp, p.file);
         p.ln("dp.out_ln", c);
         p.linear("dp.fc1", c, c);
@@ -275,7 +342,10 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
         p.done();
     }
     {   // ---- text encoder: embedding, ConvNeXt x n, {self-attention, FFN} x n, style cross-attention x n, LayerNorm, projection ---
-        const std::vector<Tok> toks = weighted_nodes(tem, "text_encoder.onnx");
+        std::string gelu;
+        const std::vector<Tok> toks = weighted_nodes(tem, "text_encoder.onnx", &gelu);
+        if (!gelu.empty() && !r.gelu.empty() && gelu != r.gelu) r.notes += "text_encoder.onnx writes GELU as '" + gelu + "', an earlier graph as '" + r.gelu + "'; ";
+        if (r.gelu.empty()) r.gelu = gelu;
         Parser p{toks, "text_encoder.onnx", "te", r};
         a.te_conv_blocks = a.te_attn_blocks = a.te_style_blocks = 0;
         const Tok* e = p.peek();
@@ -310,14 +380,17 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
                 ++a.te_style_blocks;
             }
         }
-        set_heads(r, a.te_heads, "te_heads", heads, c);
+        set_heads(r, a.te_heads, "te_heads", heads, c, heads_explicit);
         p.ln("te.out_ln", c);
         const int odim = p.linear("te.proj", -1, c).out;
         agree("te_out_dim (rows of te.proj)", odim, base.te_out_dim, p.file);
         p.done();
     }
     {   // ---- vector estimator ---------------------------------------------------------------------------------------------
-        const std::vector<Tok> toks = weighted_nodes(vem, "vector_estimator.onnx");
+        std::string gelu;
+        const std::vector<Tok> toks = weighted_nodes(vem, "vector_estimator.onnx", &gelu);
+        if (!gelu.empty() && !r.gelu.empty() && gelu != r.gelu) r.notes += "vector_estimator.onnx writes GELU as '" + gelu + "', an earlier graph as '" + r.gelu + "'; ";
+        if (r.gelu.empty()) r.gelu = gelu;
         Parser p{toks, "vector_estimator.onnx", "ve", r};
         a.ve_main_blocks = a.ve_tail_blocks = 0;
         const Tok& in = p.linear("ve.in", -1, -1);
@@ -360,13 +433,16 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
             if (!heads) heads = h;
             ++a.ve_main_blocks;
         }
-        set_heads(r, a.ve_heads, "ve_heads", heads, c);
+        set_heads(r, a.ve_heads, "ve_heads", heads, c, heads_explicit);
         p.ln("ve.out_ln", c);
         p.linear("ve.out", D, c);
         p.done();
     }
     {   // ---- vocoder: k-tap input conv, ConvNeXt x n (per-block dilation), LayerNorm, head --------------------------------------
-        const std::vector<Tok> toks = weighted_nodes(vom, "vocoder.onnx");
+        std::string gelu;
+        const std::vector<Tok> toks = weighted_nodes(vom, "vocoder.onnx", &gelu);
+        if (!gelu.empty() && !r.gelu.empty() && gelu != r.gelu) r.notes += "vocoder.onnx writes GELU as '" + gelu + "', an earlier graph as '" + r.gelu + "'; ";
+        if (r.gelu.empty()) r.gelu = gelu;
         Parser p{toks, "vocoder.onnx", "vo", r};
         a.vo_blocks = 0;
         const Tok* e = p.peek();
@@ -389,7 +465,27 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
         agree("base_chunk_size (rows of vo.head)", chunk, base.base_chunk_size, p.file);
         p.done();
     }
+    if (r.gelu == "tanh")
+        r.notes += "the graphs spell GELU with Tanh (the tanh approximation): this engine computes the erf form in fp32 and f16 and the tanh form in bf16 "
+                   "(|difference| <= 5e-4 absolute, kernels_dev.hpp); ";
     return r;
+}
+
+bool apply_arch_overrides(const std::string& dir, stn_arch& a) {
+    std::ifstream f(dir + "/stn_weight_map.json", std::ios::binary);
+    if (!f.is_open()) return false;
+    const std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const json::Value man = json::parse(text);
+    if (man.has("tensors") || !man.has("arch")) return false;
+    static const std::pair<const char*, int32_t stn_arch::*> fields[] = {
+        {"te_heads", &stn_arch::te_heads}, {"dp_heads", &stn_arch::dp_heads}, {"ve_heads", &stn_arch::ve_heads}};
+    for (const auto& kv : man.at("arch").obj) {
+        bool ok = false;
+        for (const auto& fld : fields) if (kv.first == fld.first) { a.*(fld.second) = kv.second.as_int(); ok = true; }
+        if (!ok) throw std::runtime_error("stn_weight_map.json without a \"tensors\" table may state only the head counts (te_heads, dp_heads, ve_heads), which no weight shape "
+                                          "shows; \"" + kv.first + "\" comes out of the graphs");
+    }
+    return true;
 }
 
 stn_arch arch_from_config(const std::string& path) {
@@ -427,11 +523,12 @@ void check_all_io_names(const Model& dp, const Model& te, const Model& ve, const
 }
 
 std::string bind_dir_json(const std::string& dir) {
-    const stn_arch base = arch_from_config(dir + "/tts.json");
+    stn_arch base = arch_from_config(dir + "/tts.json");
+    const bool heads_explicit = apply_arch_overrides(dir, base);
     const Model dp = onnx::parse_file(dir + "/duration_predictor.onnx"), te = onnx::parse_file(dir + "/text_encoder.onnx"),
                 ve = onnx::parse_file(dir + "/vector_estimator.onnx"), vo = onnx::parse_file(dir + "/vocoder.onnx");
     check_all_io_names(dp, te, ve, vo);
-    const Result r = bind(base, dp, te, ve, vo);
+    const Result r = bind(base, dp, te, ve, vo, heads_explicit);
     auto esc = [](const std::string& s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o.push_back('\\'); o.push_back(c); } return o; };
     std::ostringstream o;
     const stn_arch& a = r.arch;
@@ -451,10 +548,10 @@ std::string bind_dir_json(const std::string& dir) {
     bool first = true;
     for (const auto& kv : r.tensors) {
         o << (first ? "" : ",") << "\"" << kv.first << "\":{\"from\":\"" << esc(kv.second.from) << "\",\"transpose\":" << (kv.second.transpose ? "true" : "false")
-          << ",\"zeros\":" << (kv.second.t ? "false" : "true") << "}";
+          << ",\"zeros\":" << (kv.second.t ? "false" : "true") << ",\"row0\":" << kv.second.row0 << ",\"rows_total\":" << kv.second.rows_total << "}";
         first = false;
     }
-    o << "},\"notes\":\"" << esc(r.notes) << "\"}";
+    o << "},\"gelu\":\"" << esc(r.gelu) << "\",\"notes\":\"" << esc(r.notes) << "\"}";
     return o.str();
 }
 
@@ -472,14 +569,19 @@ std::vector<float> fetch(const Bound& b, const std::string& canonical, int rows,
     const size_t n = (size_t)rows * cols;
     if (!b.t) return std::vector<float>(n, 0.f);
     std::vector<float> v = onnx::to_float(*b.t);
-    if (v.size() != n)
-        throw std::runtime_error(canonical + ": " + b.from + " has " + std::to_string(v.size()) + " elements, descriptor wants " + std::to_string(rows) + "x" + std::to_string(cols));
+    // a row block of a fused projection: the initializer holds rows_total x cols (1-D tensors, the biases: rows_total elements)
+    const bool vec = rows == 1 && b.rows_total > 0;  // canonical vectors are [1][n]
+    const int full_rows = b.rows_total ? (vec ? 1 : b.rows_total) : rows, full_cols = vec ? b.rows_total : cols;
+    if (v.size() != (size_t)full_rows * full_cols)
+        throw std::runtime_error(canonical + ": " + b.from + " has " + std::to_string(v.size()) + " elements, descriptor wants " + std::to_string(full_rows) + "x" + std::to_string(full_cols));
     if (b.transpose) {
-        std::vector<float> w(n);
-        for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) w[(size_t)r * cols + c] = v[(size_t)c * rows + r];
+        std::vector<float> w(v.size());
+        for (int r = 0; r < full_rows; ++r) for (int c = 0; c < full_cols; ++c) w[(size_t)r * full_cols + c] = v[(size_t)c * full_rows + r];
         v.swap(w);
     }
-    return v;
+    if (!b.rows_total) return v;
+    if (vec) return std::vector<float>(v.begin() + b.row0, v.begin() + b.row0 + cols);
+    return std::vector<float>(v.begin() + (size_t)b.row0 * cols, v.begin() + (size_t)(b.row0 + rows) * cols);
 }
 
 }  // namespace graphbind

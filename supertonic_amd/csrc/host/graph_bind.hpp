@@ -22,18 +22,29 @@ namespace graphbind {
 struct Bound {
     const onnx::Tensor* t = nullptr;  // nullptr: the graph has no such tensor (a projection without bias) -> zeros
     bool transpose = false;           // stored [cols][rows] (MatMul / Gemm with transB = 0)
+    // a fused projection (one MatMul for q|k|v or k|v, split afterwards): this tensor is rows [row0, row0 + rows) of the
+    // initializer's `rows_total` canonical rows; rows_total == 0: the whole initializer
+    int row0 = 0, rows_total = 0;
     std::string from;                 // "<file>: node #i <op> '<name>' input '<initializer>'"
 };
 
 struct Result {
     stn_arch arch;
     std::map<std::string, Bound> tensors;  // canonical name -> initializer
-    std::string notes;                     // what could not be read from the graphs and was left at the descriptor's value
+    std::string notes;                     // remarks that do not stop a load (e.g. the GELU form the graphs spell out)
+    std::string gelu;                      // "erf", "tanh", "op" (a Gelu node), "" (none seen): how the graphs write the activation
 };
 
 // `base`: the descriptor as tts.json (and the defaults) give it; the graphs override what their shapes determine and must agree
 // with what tts.json states.  Throws std::runtime_error with the diff described above.
-Result bind(const stn_arch& base, const onnx::Model& dp, const onnx::Model& te, const onnx::Model& ve, const onnx::Model& vo);
+// Variants of the same layout that exporters produce are accepted: LayerNormalization as one node or decomposed
+// (ReduceMean / Sub / Pow / ReduceMean / Add / Sqrt / Div / Mul gamma / Add beta), q / k / v as separate projections or fused
+// (one projection of 3C or 2C rows split afterwards), pointwise projections as Conv k=1, MatMul(+Add) in either operand order
+// with Transposes around it, or Gemm with either transB, GELU as a Gelu node or spelled out with Erf or Tanh.
+// heads_explicit: base's *_heads fields were stated by the caller (stn_weight_map.json "arch"); otherwise a head count that the
+// graphs do not carry (no [batch, length, heads, head_dim] Reshape constant inside an attention block) is an ERROR, not a default.
+Result bind(const stn_arch& base, const onnx::Model& dp, const onnx::Model& te, const onnx::Model& ve, const onnx::Model& vo,
+            bool heads_explicit = false);
 
 // The descriptor as tts.json states it: the four fields every host reads (/root/reference/cpp/helper.cpp:811-815) and the style /
 // projection dims of /root/reference/go/helper.go:45-78 when present; everything else at stn_arch_default's values.
@@ -41,7 +52,10 @@ stn_arch arch_from_config(const std::string& tts_json_path);
 
 // bind() over the four graph files of `dir` (+ check_io_names), as JSON: {"arch": {...}, "tensors": {canonical: {"from": "...",
 // "transpose": bool}}, "notes": "..."} — what stn_load_dir would load, without a device.
+// An optional stn_weight_map.json WITHOUT a "tensors" table only states descriptor fields ("arch": {"ve_heads": 4, ...}) for the walk.
 std::string bind_dir_json(const std::string& dir);
+// {"arch": {...}} of <dir>/stn_weight_map.json applied to `a` when the file exists and has no "tensors" table; returns whether it did
+bool apply_arch_overrides(const std::string& dir, stn_arch& a);
 
 // Graph input / output names every host feeds and fetches (/root/reference/cpp/helper.cpp:547-672); throws naming the difference.
 void check_io_names(const onnx::Model& m, const std::string& file, const std::vector<std::string>& inputs,

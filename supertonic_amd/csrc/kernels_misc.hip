@@ -568,7 +568,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
                                                                  const float* __restrict__ b2, const float* __restrict__ gamma,
                                                                  const float* __restrict__ rowvec, int rv_ld, const float* __restrict__ w_t,
                                                                  const float* __restrict__ bias, int dil, const float* __restrict__ g,
-                                                                 const float* __restrict__ bt, float eps, OutT* __restrict__ y,
+                                                                 const float* __restrict__ bt, float eps, float inv_c, OutT* __restrict__ y,
                                                                  const int* __restrict__ seqlen, const int* __restrict__ row_off,
                                                                  unsigned long long* __restrict__ ts) {
     extern __shared__ __attribute__((aligned(16))) float fold_sm[];
@@ -586,7 +586,8 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     const int w0 = max(t0 - HALF * dil, 0), w1 = min(t1 + HALF * dil, Lv), nw = w1 - w0;
     const int tid = threadIdx.x, C8 = C >> 3, C4 = C >> 2;
     // the parameters of phase 2 as one LDS block behind the image: [K taps][C] | conv bias | LayerNorm g | LayerNorm b
-    float* const wsm = fold_sm + (size_t)(FOLD_TCH + (K - 1) * dil) * C;
+    float* const zrow = fold_sm + (size_t)(FOLD_TCH + (K - 1) * dil) * C;  // a row of zeros: what a tap outside the sequence reads
+    float* const wsm = zrow + C;
     constexpr int NPV = (K + 3 + 7) / 8;  // float4 per thread: (K + 3) * C4 <= NPV * FOLD_NT for C <= 512, K <= 7 ... checked by the launcher
     float4 pv[NPV];
 #pragma unroll
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
         const int q = tid + i * FOLD_NT;
         if (q < (K + 3) * C4) reinterpret_cast<float4*>(wsm)[q] = pv[i];
     }
+    if (tid < C4) reinterpret_cast<float4*>(zrow)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ts) st1 = __builtin_readcyclecounter();
     __syncthreads();
     if (ts) st2 = __builtin_readcyclecounter();
@@ -659,18 +661,17 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
         for (int j = 0; j < K; ++j) {
             const int tt = tl + (j - HALF) * dil;
             const bool in = tt >= 0 && tt < Lv;  // (then w0 <= tt < w1)
-            const float4 xv = *reinterpret_cast<const float4*>(fold_sm + (size_t)((in ? tt : tl) - w0) * C + cq * 4);
+            const float4 xv = *reinterpret_cast<const float4*>((in ? fold_sm + (size_t)(tt - w0) * C : zrow) + cq * 4);
             const float4 wv = ws4[j * C4 + cq];
-            const float keep = in ? 1.f : 0.f;
-            a.x = fmaf(wv.x * keep, xv.x, a.x); a.y = fmaf(wv.y * keep, xv.y, a.y);
-            a.z = fmaf(wv.z * keep, xv.z, a.z); a.w = fmaf(wv.w * keep, xv.w, a.w);
+            a.x = fmaf(wv.x, xv.x, a.x); a.y = fmaf(wv.y, xv.y, a.y);
+            a.z = fmaf(wv.z, xv.z, a.z); a.w = fmaf(wv.w, xv.w, a.w);
         }
         h[i] = c4 < C4 ? a : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < FOLD_NSLOT; ++i) s += (h[i].x + h[i].y) + (h[i].z + h[i].w);
-    const float mean = half_wave_sum(s) / (float)C;
+    const float mean = half_wave_sum(s) * inv_c;
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < FOLD_NSLOT; ++i)
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
             const float dx = h[i].x - mean, dy = h[i].y - mean, dz = h[i].z - mean, dw = h[i].w - mean;
             v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
-    const float rstd = rsqrtf(half_wave_sum(v) / (float)C + eps);
+    const float rstd = rsqrtf(half_wave_sum(v) * inv_c + eps);
     if (live) {
 #pragma unroll
         for (int i = 0; i < FOLD_NSLOT; ++i) {
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     }
 }
 
-static size_t fold_dwconv_lds(int C, int k, int dil) { return ((size_t)(FOLD_TCH + (k - 1) * dil) + (size_t)(k + 3)) * C * 4; }  // image + parameter block
+static size_t fold_dwconv_lds(int C, int k, int dil) { return ((size_t)(FOLD_TCH + (k - 1) * dil) + 1 + (size_t)(k + 3)) * C * 4; }  // image + zero row + parameter block
 bool fold_dwconv_ln_supported(int C, int k, int dil) {
     return C % 8 == 0 && C <= 512 && (k == 5 || k == 7) && dil >= 1 && fold_dwconv_lds(C, k, dil) <= 160 * 1024;
 }
@@ -720,7 +721,7 @@ static void launch_fold_dwconv_ln_t2(hipStream_t s, const float* x_in, float* x_
                                           160 * 1024), "hipFuncSetAttribute(fold_dwconv_ln)");
     const int cps = (L + FOLD_TCH - 1) / FOLD_TCH;
     STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil), s, x_in, x_out, cps, C,
-                static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, y, seqlen, row_off, f.ts);
+                static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, 1.0f / (float)C, y, seqlen, row_off, f.ts);
 }
 template <typename OutT, bool F16, int K, bool RV>
 static void launch_fold_dwconv_ln_t(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,

@@ -55,6 +55,26 @@ class GatherPlan:
                      for _ in range(slots)]
         self.work = [None] * slots
 
+    @classmethod
+    def local(cls, shapes, device, dtype):
+        """The ROOT's side of a plan for the given per-rank [B, W] shapes, without a process group: the receive buffers a gather
+        into rank 0 would fill, for producers that run one after another in this process (the single-GPU rehearsal of the
+        8-shard job, tests/test_gpu_configs.py).  `bufs[0][r]` / `result()` as after a real gather; `wav_ptr(r)` addresses rank
+        r's block."""
+        import torch
+        self = cls.__new__(cls)
+        self.dst, self.rank, self.world = 0, 0, len(shapes)
+        self.shapes = [(int(b), int(w)) for b, w in shapes]
+        self.Bm, self.Wm = max(s[0] for s in self.shapes), max(s[1] for s in self.shapes)
+        isz = torch.empty((), dtype=dtype).element_size()
+        self.tail = 16 // isz
+        self.Wm = (self.Wm + self.tail - 1) // self.tail * self.tail
+        self.stride = self.Wm + self.tail
+        self.bufs = [[torch.zeros((self.Bm, self.stride), dtype=dtype, device=device) for _ in range(self.world)]]
+        self.payload = self.bufs[0]  # wav_ptr(r) / set_durations(d, r) write rank r's block in place
+        self.work = [None] * self.world
+        return self
+
     def _dur_view(self, t):
         import torch
         return t[:, self.Wm:].view(torch.float32)[:, 0]

@@ -60,3 +60,20 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 hits = [b for b in banned if b in txt]
                 assert not hits, (f, hits)
+
+
+def test_fused_forms_respect_the_lds_budget():
+    """a block shape whose K4 workgroup would need more than 160 KiB of LDS (ring + biases) must fall back to the two
+    GEMM launches at descriptor level, never fail at kernel launch (possibly inside a stream capture)."""
+    lib = binding.load()
+    BF16, F16, F32 = 1, 2, 0
+    assert lib.stn_ffn_fused_forms(BF16, 512, 2048) == 1 and lib.stn_ffn_fused_forms(F16, 512, 2048) == 1   # the vocoder's block
+    assert lib.stn_ffn_fused_forms(BF16, 384, 1536) == 2                                                      # the estimator's: K4 and K4-split
+    assert lib.stn_ffn_fused_forms(BF16, 512, 7168) == 1 and lib.stn_ffn_fused_forms(BF16, 512, 8192) == 0    # 4*512*64 + (8192 + 1024)*4 > 160 KiB
+    assert lib.stn_ffn_fused_forms(F32, 512, 2048) == 0 and lib.stn_ffn_fused_forms(BF16, 256, 1024) == 0
+    assert lib.stn_ffn_fused_forms(BF16, 384, 1472) == 1  # I / 32 not a multiple of 8: no hidden split
+
+
+def test_hip_runtime_versions_are_reported():
+    info = binding.runtime_info()
+    assert info["hip_built"] > 60000000 and info["lib"].endswith("libstn.so")

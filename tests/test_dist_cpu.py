@@ -128,3 +128,22 @@ def test_workload_is_deterministic():
     assert a == b and all(t[0].isupper() and t.endswith(".") and len(t.split()) == 10 for t in a)
     d = workload.forced_durations([workload.C1_SENTENCE])
     assert abs(float(d[0]) - 53 / 15.0) < 1e-6  # 53 chars -> 3.53 s before /speed
+
+
+def test_gather_plan_local_is_the_roots_receive_side():
+    """GatherPlan.local: the root's buffers for given per-rank shapes with no process group (what the single-GPU rehearsal of the
+    8-shard job fills rank by rank): same row stride / duration tail / result() views as after a real gather."""
+    import torch
+    from supertonic_amd.dist import GatherPlan
+    shapes = [(3, 40), (2, 56), (1, 8)]
+    plan = GatherPlan.local(shapes, torch.device("cpu"), torch.int16)
+    assert plan.world == 3 and plan.Bm == 3 and plan.Wm == 56 and plan.stride == 56 + 8 and plan.stride * 2 % 16 == 0
+    for r, (b, w) in enumerate(shapes):
+        blk = plan.payload[r]
+        blk[:b, :w] = (torch.arange(b * w, dtype=torch.int32).reshape(b, w) % 1000 + 7 * r).to(torch.int16)
+        plan.set_durations(torch.arange(b, dtype=torch.float32) + 10 * r, r)
+    wavs, durs = plan.result(0)
+    for r, (b, w) in enumerate(shapes):
+        exp = (torch.arange(b * w, dtype=torch.int32).reshape(b, w) % 1000 + 7 * r).to(torch.int16)
+        assert wavs[r].shape == (b, w) and torch.equal(wavs[r], exp)
+        assert torch.equal(durs[r], torch.arange(b, dtype=torch.float32) + 10 * r)
