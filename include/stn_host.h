@@ -43,9 +43,14 @@ int64_t stn_sanitize_filename(const char* text, int max_len, char* out, size_t c
 int64_t stn_onnx_summary(const char* path, char* out, size_t cap);
 /* What stn_load_dir binds when the directory has no stn_weight_map.json, without a device: the descriptor derived from the four
    graphs' weighted nodes (+ tts.json) and, per canonical tensor, the initializer it was bound to — JSON {"arch": {..},
-   "tensors": {name: {"from": "...", "transpose": bool, "zeros": bool}}, "notes": "..."}.  Fails (STN_ERR_IO, stn_host_last_error) with
+   "tensors": {name: {"from": "...", "transpose": bool, "zeros": bool, "row0": int, "rows_total": int}}, "gelu": "erf|tanh|op|", "notes": "..."}
+   (rows_total > 0: a row block of a fused q|k|v / k|v projection).  A stn_weight_map.json without a "tensors" table may state the head
+   counts the graphs do not carry; with one, it replaces the walk.  Fails (STN_ERR_IO, stn_host_last_error) with
    the first node that does not fit the layout.  Stands in for Ort::Session's own graph loading, cpp/helper.cpp:784-795. */
 int64_t stn_bind_graphs(const char* onnx_dir, char* out, size_t cap);
+/* One canonical tensor of that binding as the engine would load it (fp32, canonical orientation: transposed / cut out of a fused
+   projection as bound): returns the element count (0 for a tensor the graph does not have: zeros), copies when cap suffices. */
+int64_t stn_bound_tensor(const char* onnx_dir, const char* canonical_name, float* out, size_t cap);
 
 int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap);
 int stn_write_wav(const char* path, const float* audio, size_t n, int sample_rate);

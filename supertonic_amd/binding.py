@@ -202,6 +202,10 @@ class Engine:
         self._ck(self._lib.stn_load_synthetic(self._h, ctypes.byref(arch), seed))
         self.arch = arch
 
+    def last_error(self) -> str:
+        """stn_last_error: the last failure's text — or, after a successful manifest-less stn_load_dir, its notes."""
+        return (self._lib.stn_last_error(self._h) or b"").decode()
+
     def load_dir(self, onnx_dir: str):
         self._ck(self._lib.stn_load_dir(self._h, onnx_dir.encode()))
         a = StnArch()

@@ -204,9 +204,9 @@ struct Parser {
         o << ". Derived so far: " << arch_so_far(r.arch, stage);
         throw std::runtime_error(o.str());
     }
-    void bind(const std::string& name, const Tensor* ten, bool transpose, const Tok& tok, int row0 = 0, int rows_total = 0) {
+    void bind(const std::string& name, const Tensor* ten, bool transpose, const Tok& tok, int row0 = 0, int rows_total = 0, int rows_per_part = 0) {
         Bound b;
-        b.t = ten; b.transpose = transpose; b.row0 = row0; b.rows_total = rows_total;
+        b.t = ten; b.transpose = transpose; b.row0 = row0; b.rows_total = rows_total; b.nrows = rows_total ? rows_per_part : 0;
         b.from = tok.where + (ten ? " initializer '" + ten->name + "' " + dims_str(ten) : " (no such input: zeros)");
         if (rows_total) b.from += " rows " + std::to_string(row0) + ".. of " + std::to_string(rows_total);
         r.tensors[name] = b;
@@ -260,8 +260,8 @@ struct Parser {
             const int n = (int)parts.size();
             int j = 0;
             for (const char* part : parts) {
-                bind(name + "." + part + ".w", tk.w, tk.transposed, tk, j * c, n * c);
-                bind(name + "." + part + ".b", tk.b, false, tk, j * c, tk.b ? n * c : 0);
+                bind(name + "." + part + ".w", tk.w, tk.transposed, tk, j * c, n * c, c);
+                bind(name + "." + part + ".b", tk.b, false, tk, j * c, tk.b ? n * c : 0, c);
                 ++j;
             }
             h(tk);
@@ -360,8 +360,21 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
         // an attention block (LN q k v o) followed by LN + two projections is a self-attention block with its FFN; without them it
         // is a style cross-attention block; LN + ONE projection ends the graph
         int ffn = -1;
-        while (p.next_is(LN) && p.next_is(LINEAR, 1) && p.next_is(LINEAR, 2)) {
-            const bool has_ffn = p.next_is(LN, 5) && p.next_is(LINEAR, 6) && p.next_is(LINEAR, 7) && !p.next_is(LINEAR, 8);
+        // projections of the attention block whose LayerNorm sits `at` tokens ahead: 4 (q, k, v, o), 3 (q, fused k|v, o), 2 (fused
+        // q|k|v, o — told from an FFN's two projections by the shapes: 3c <- c then c <- c); 0: not an attention block
+        auto attn_linears = [&](size_t at) -> int {
+            if (!p.next_is(LN, at)) return 0;
+            int n = 0;
+            while (p.next_is(LINEAR, at + 1 + n)) ++n;
+            if (n == 2) {
+                const Tok *l1 = p.peek(at + 1), *l2 = p.peek(at + 2);
+                return (l1->out == 3 * c && l1->in == c && l2->out == c && l2->in == c) ? 2 : 0;
+            }
+            return (n == 3 || n == 4) ? n : 0;
+        };
+        while (const int nl = attn_linears(0)) {
+            const size_t f = 1 + (size_t)nl;  // where an FFN's LayerNorm would sit
+            const bool has_ffn = p.next_is(LN, f) && p.next_is(LINEAR, f + 1) && p.next_is(LINEAR, f + 2) && !p.next_is(LINEAR, f + 3) && attn_linears(f) == 0;
             if (has_ffn) {
                 if (a.te_style_blocks) p.fail("te.st" + std::to_string(a.te_style_blocks), "a style cross-attention block (self-attention blocks come first)");
                 const std::string n = S("te.sa%d", a.te_attn_blocks);
@@ -582,6 +595,31 @@ std::vector<float> fetch(const Bound& b, const std::string& canonical, int rows,
     if (!b.rows_total) return v;
     if (vec) return std::vector<float>(v.begin() + b.row0, v.begin() + b.row0 + cols);
     return std::vector<float>(v.begin() + (size_t)b.row0 * cols, v.begin() + (size_t)(b.row0 + rows) * cols);
+}
+
+std::vector<float> fetch_canonical(const Bound& b, const std::string& canonical) {
+    if (!b.t) return {};
+    std::vector<int64_t> d;
+    for (int64_t x : b.t->dims) if (x != 1) d.push_back(x);
+    if (d.size() <= 1) {  // a vector (bias, LayerNorm parameter, scale) or a block of one
+        const int n = (int)b.t->numel();
+        return fetch(b, canonical, 1, b.rows_total ? b.nrows : n);
+    }
+    int64_t rest = 1;
+    for (size_t i = 1; i < d.size(); ++i) rest *= d[i];
+    const int rows = (int)(b.transpose ? d[1] : d[0]), cols = (int)(b.transpose ? d[0] : rest);
+    return fetch(b, canonical, b.rows_total ? b.nrows : rows, cols);
+}
+
+std::vector<float> bound_tensor_of_dir(const std::string& dir, const std::string& canonical) {
+    stn_arch base = arch_from_config(dir + "/tts.json");
+    const bool heads_explicit = apply_arch_overrides(dir, base);
+    const Model dp = onnx::parse_file(dir + "/duration_predictor.onnx"), te = onnx::parse_file(dir + "/text_encoder.onnx"),
+                ve = onnx::parse_file(dir + "/vector_estimator.onnx"), vo = onnx::parse_file(dir + "/vocoder.onnx");
+    const Result r = bind(base, dp, te, ve, vo, heads_explicit);
+    auto it = r.tensors.find(canonical);
+    if (it == r.tensors.end()) throw std::runtime_error("no canonical tensor \"" + canonical + "\" in the binding of " + dir);
+    return fetch_canonical(it->second, canonical);
 }
 
 }  // namespace graphbind

@@ -24,7 +24,7 @@ struct Bound {
     bool transpose = false;           // stored [cols][rows] (MatMul / Gemm with transB = 0)
     // a fused projection (one MatMul for q|k|v or k|v, split afterwards): this tensor is rows [row0, row0 + rows) of the
     // initializer's `rows_total` canonical rows; rows_total == 0: the whole initializer
-    int row0 = 0, rows_total = 0;
+    int row0 = 0, rows_total = 0, nrows = 0;
     std::string from;                 // "<file>: node #i <op> '<name>' input '<initializer>'"
 };
 
@@ -66,6 +66,11 @@ void check_all_io_names(const onnx::Model& dp, const onnx::Model& te, const onnx
 // Fetch one bound tensor as canonical row-major [rows][cols] fp32 (transposing / zero-filling as bound); checks the element count
 // and, for matrices, the stored dims against rows x cols.
 std::vector<float> fetch(const Bound& b, const std::string& canonical, int rows, int cols);
+// The same values without a descriptor (host tools / tests): canonical orientation and row block are taken from the initializer's own
+// dims ([out][in...] or, transposed, [in][out]); an unbound tensor (zeros) comes back empty.
+std::vector<float> fetch_canonical(const Bound& b, const std::string& canonical);
+// bind() over <dir> as bind_dir_json does, returning one canonical tensor's values
+std::vector<float> bound_tensor_of_dir(const std::string& dir, const std::string& canonical);
 
 }  // namespace graphbind
 }  // namespace stn

@@ -108,6 +108,16 @@ int64_t stn_bind_graphs(const char* onnx_dir, char* out, size_t cap) {
     return rc < 0 ? STN_ERR_IO : rc;
 }
 
+int64_t stn_bound_tensor(const char* onnx_dir, const char* canonical, float* out, size_t cap) {
+    const int64_t rc = guarded([&]() -> int64_t {
+        if (!onnx_dir || !canonical) throw std::runtime_error("null argument");
+        const std::vector<float> v = stn::graphbind::bound_tensor_of_dir(onnx_dir, canonical);
+        if (out && cap >= v.size()) std::memcpy(out, v.data(), v.size() * sizeof(float));
+        return (int64_t)v.size();
+    });
+    return rc < 0 ? STN_ERR_IO : rc;
+}
+
 int64_t stn_wav_encode(const float* audio, size_t n, int sample_rate, unsigned char* out, size_t cap) {
     return guarded([&]() -> int64_t {
         if (!audio && n) throw std::runtime_error("null argument");

@@ -75,13 +75,14 @@ Tensor parse_tensor(Reader r) {
     }
     return t;
 }
-// AttributeProto{name = 1, i = 3, t = 5, ints = 8}: integers into n.ints, a tensor (Constant's "value") into *tensor_out
+// AttributeProto{name = 1, i = 3, s = 4, t = 5, ints = 8}: integers into n.ints, strings into n.strs, a tensor (Constant's "value") into *tensor_out
 void parse_attribute(Reader r, Node& n, std::vector<Tensor>* tensor_out) {
     std::string name;
     std::vector<int64_t> vals;
     bool have = false;
     Tensor t;
-    bool have_t = false;
+    bool have_t = false, have_s = false;
+    std::string sval;
     while (!r.done()) {
         const uint64_t key = r.varint();
         const int field = (int)(key >> 3), wire = (int)(key & 7);
@@ -89,9 +90,11 @@ void parse_attribute(Reader r, Node& n, std::vector<Tensor>* tensor_out) {
         else if (field == 3 && wire == 0) { vals.push_back((int64_t)r.varint()); have = true; }
         else if (field == 8) { repeated_scalar(r, wire, vals, [](Reader& s) { return (int64_t)s.varint(); }, 0); have = true; }
         else if (field == 5 && wire == 2) { t = parse_tensor(r.sub()); have_t = true; }
+        else if (field == 4 && wire == 2) { sval = r.str(); have_s = true; }
         else r.skip(wire);
     }
     if (have) n.ints[name] = std::move(vals);
+    if (have_s) n.strs[name] = std::move(sval);
     if (have_t && tensor_out && name == "value") tensor_out->push_back(std::move(t));
 }
 Node parse_node(Reader r, std::vector<Tensor>* constants) {

@@ -33,6 +33,8 @@ struct Node {
     std::map<std::string, std::vector<int64_t>> ints;  // INT and INTS attributes (group, dilations, kernel_shape, transB, axis ...)
     const std::vector<int64_t>* attr(const std::string& k) const { auto it = ints.find(k); return it == ints.end() ? nullptr : &it->second; }
     int64_t attr_i(const std::string& k, int64_t dflt) const { auto* v = attr(k); return v && !v->empty() ? (*v)[0] : dflt; }
+    std::map<std::string, std::string> strs;           // STRING attributes (Gelu's "approximate")
+    std::string attr_s(const std::string& k, const std::string& dflt) const { auto it = strs.find(k); return it == strs.end() ? dflt : it->second; }
 };
 
 struct Model {

@@ -148,6 +148,19 @@ def bind_graphs(onnx_dir: str) -> dict:
     return json.loads(buf.value.decode())
 
 
+def bound_tensor(onnx_dir: str, name: str) -> np.ndarray:
+    """One canonical tensor of the manifest-less binding, flat fp32, as the engine would load it (host only)."""
+    L = _lib()
+    L.stn_bound_tensor.restype = ctypes.c_int64
+    L.stn_bound_tensor.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    n = L.stn_bound_tensor(onnx_dir.encode(), name.encode(), None, 0)
+    if n < 0:
+        raise OSError(L.stn_host_last_error().decode())
+    out = np.empty(n, np.float32)
+    L.stn_bound_tensor(onnx_dir.encode(), name.encode(), out.ctypes.data, n)
+    return out
+
+
 def wav_bytes(audio, sample_rate: int) -> bytes:
     L = _lib()
     a = np.ascontiguousarray(audio, np.float32)

@@ -16,10 +16,36 @@ IO = {"dp": (["text_ids", "style_dp", "text_mask"], ["duration"]), "te": (["text
 
 
 class Graph:
-    def __init__(self, stage, tensor, breaks):
+    """variants (exporter spellings of the same layout, all must bind to the same tensors):
+         ln   = "node" | "decomposed" | "decomposed_nobeta"   LayerNormalization as one node, or ReduceMean / Sub / Pow / ReduceMean / Add eps /
+                                                              Sqrt / Div / Mul gamma / Add beta (beta dropped in the last form)
+         qkv  = "separate" | "fused"                          q, k, v projections separately, or one 3C (self) / 2C (context k|v) projection + Split
+         pw   = "mixed" | "matmul_transpose"                  projections in four encodings by position, or always Transpose -> MatMul -> Add -> Transpose
+         gelu = "op" | "op_tanh" | "erf" | "tanh"             a Gelu node (approximate = none / tanh), or the Erf / Tanh formulas spelled out"""
+
+    def __init__(self, stage, tensor, breaks, variants=None):
         self.stage, self.tensor, self.breaks = stage, tensor, breaks
+        self.var = dict(ln="node", qkv="separate", pw="mixed", gelu="op")
+        self.var.update(variants or {})
         self.inits, self.nodes, self.n = [], [], 0
         self.cur = IO[stage][0][0]
+
+    def scalar(self, v):
+        return self.init("scalar", np.array(v, np.float32).reshape(()))
+
+    def gelu(self):
+        g, x = self.var["gelu"], self.cur
+        if g == "op":
+            self.plain("Gelu")
+        elif g == "op_tanh":
+            self.cur = self.op("Gelu", [x], [ow.attr_str("approximate", "tanh")])
+        elif g == "erf":
+            e = self.op("Erf", [self.op("Div", [x, self.scalar(np.sqrt(2.0))])])
+            self.cur = self.op("Mul", [self.op("Mul", [x, self.op("Add", [e, self.scalar(1.0)])]), self.scalar(0.5)])
+        else:
+            x3 = self.op("Pow", [x, self.scalar(3.0)])
+            t = self.op("Tanh", [self.op("Mul", [self.op("Add", [x, self.op("Mul", [x3, self.scalar(0.044715)])]), self.scalar(np.sqrt(2.0 / np.pi))])])
+            self.cur = self.op("Mul", [self.op("Mul", [x, self.op("Add", [t, self.scalar(1.0)])]), self.scalar(0.5)])
 
     def val(self):
         self.n += 1
@@ -54,8 +80,17 @@ class Graph:
     def linear(self, name, out, inp, src=None):
         x = src if src is not None else self.cur
         W, b = self.w(name + ".w", (out, inp)), self.w(name + ".b", (out,))
+        return self.linear_wb(name, W, b, x, src is None)
+
+    def linear_wb(self, name, W, b, x, advance=True):
+        out, inp = W.shape
         enc = len(self.nodes) % 4
-        if enc == 0:
+        if self.var["pw"] == "matmul_transpose":  # what a Conv1d(k=1) becomes when an exporter lowers it: Transpose -> MatMul -> Add -> Transpose
+            y = self.op("Transpose", [x], [ow.attr_ints("perm", [0, 2, 1])])
+            y = self.op("MatMul", [y, self.init(name, W.T)])
+            y = self.op("Add", [y, self.init(name, b)])
+            y = self.op("Transpose", [y], [ow.attr_ints("perm", [0, 2, 1])])
+        elif enc == 0:
             y = self.op("Conv", [x, self.init(name, W.reshape(out, inp, 1)), self.init(name, b)], [ow.attr_ints("kernel_shape", [1])])
         elif enc == 1:
             y = self.op("MatMul", [x, self.init(name, W.T)])
@@ -64,13 +99,24 @@ class Graph:
             y = self.op("Gemm", [x, self.init(name, W), self.init(name, b)], [ow.attr_int("transB", 1)])
         else:
             y = self.op("Gemm", [x, self.init(name, W.T), self.init(name, b)])
-        if src is None:
+        if advance:
             self.cur = y
         return y
 
     def ln(self, name, C):
-        self.cur = self.op("LayerNormalization", [self.cur, self.init(name, self.w(name + ".g", (C,))), self.init(name, self.w(name + ".b", (C,)))],
-                           [ow.attr_int("axis", -1)])
+        if self.var["ln"] == "node":
+            self.cur = self.op("LayerNormalization", [self.cur, self.init(name, self.w(name + ".g", (C,))), self.init(name, self.w(name + ".b", (C,)))],
+                               [ow.attr_int("axis", -1)])
+            return
+        x = self.cur
+        mu = self.op("ReduceMean", [x], [ow.attr_ints("axes", [-1])])
+        d = self.op("Sub", [x, mu])
+        var = self.op("ReduceMean", [self.op("Pow", [d, self.scalar(2.0)])], [ow.attr_ints("axes", [-1])])
+        xh = self.op("Div", [d, self.op("Sqrt", [self.op("Add", [var, self.scalar(1e-6)])])])
+        y = self.op("Mul", [xh, self.init(name, self.w(name + ".g", (C,)))] if len(self.nodes) % 2 else [self.init(name, self.w(name + ".g", (C,))), xh])
+        if self.var["ln"] != "decomposed_nobeta":
+            y = self.op("Add", [y, self.init(name, self.w(name + ".b", (C,)))])
+        self.cur = y
 
     def convnext(self, name, C, H, k, dil):
         res = self.cur
@@ -90,7 +136,7 @@ class Graph:
         if brk == "batchnorm":
             self.cur = self.op("BatchNormalization", [self.cur] + [self.init(name, np.ones(C, np.float32)) for _ in range(4)])
         self.linear(name + ".pw1", H, C)
-        self.plain("Gelu")
+        self.gelu()
         self.linear(name + ".pw2", C, H)
         if brk != "no_gamma":
             g = self.w(name + ".gamma", (C,))
@@ -111,9 +157,20 @@ class Graph:
         self.ln(name + ".ln", C)
         kv_src = self.cur if ctx is None else ctx
         split = lambda x: self.op("Reshape", [x, self.shape_const([0, 0, heads, C // heads])]) if with_heads else self.op("Identity", [x])
-        q = split(self.linear(name + ".q", C, C, src=self.cur))
-        k = split(self.linear(name + ".k", C, Cctx, src=kv_src))
-        v = split(self.linear(name + ".v", C, Cctx, src=kv_src))
+        cat = lambda parts, suf, shp: np.concatenate([self.w(f"{name}.{p_}.{suf}", shp) for p_ in parts], 0)
+        if self.var["qkv"] == "fused" and ctx is None:  # self-attention: ONE projection of 3C rows, split afterwards
+            f = self.linear_wb(name + ".qkv", cat("qkv", "w", (C, C)), cat("qkv", "b", (C,)), self.cur, advance=False)
+            self.nodes.append(ow.node("Split", [f], [f + "_q", f + "_k", f + "_v"], f"/{self.stage}/Split_{len(self.nodes)}", [ow.attr_int("axis", -1)]))
+            q, k, v = split(f + "_q"), split(f + "_k"), split(f + "_v")
+        elif self.var["qkv"] == "fused":  # cross-attention: q alone, k | v as ONE projection of the context
+            q = split(self.linear(name + ".q", C, C, src=self.cur))
+            f = self.linear_wb(name + ".kv", cat("kv", "w", (C, Cctx)), cat("kv", "b", (C,)), kv_src, advance=False)
+            self.nodes.append(ow.node("Split", [f], [f + "_k", f + "_v"], f"/{self.stage}/Split_{len(self.nodes)}", [ow.attr_int("axis", -1)]))
+            k, v = split(f + "_k"), split(f + "_v")
+        else:
+            q = split(self.linear(name + ".q", C, C, src=self.cur))
+            k = split(self.linear(name + ".k", C, Cctx, src=kv_src))
+            v = split(self.linear(name + ".v", C, Cctx, src=kv_src))
         s = self.op("MatMul", [self.op("Transpose", [q]), self.op("Transpose", [k])])
         s = self.op("Mul", [s, self.init("scale", np.array([1.0 / np.sqrt(C // heads)], np.float32))])  # a scalar: not a weight
         o = self.op("MatMul", [self.op("Softmax", [s]), self.op("Transpose", [v])])
@@ -127,12 +184,12 @@ class Graph:
         return ow.model(self.inits, self.nodes, ins, outs, producer="pytorch")
 
 
-def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=None, io_overrides=None):
-    """Write tts.json, unicode_indexer.json and the four graphs of descriptor `a` into `tmp` (no manifest)."""
+def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=None, io_overrides=None, variants=None):
+    """Write tts.json, unicode_indexer.json and the four graphs of descriptor `a` into `tmp` (no manifest).  variants: see Graph."""
     from supertonic_amd import host
     breaks = breaks or {}
     D = a.latent_dim * a.chunk_compress_factor
-    g = Graph("dp", tensor, breaks)
+    g = Graph("dp", tensor, breaks, variants)
     g.embed("dp.emb", a.vocab_size, a.dp_dim)
     for i in range(a.dp_conv_blocks):
         g.convnext(f"dp.conv{i}", a.dp_dim, a.dp_hidden, a.dp_kernel, 1)
@@ -143,7 +200,7 @@ def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=
     g.linear("dp.fc2", 1, a.dp_dim)
     graphs = {"dp": g}
 
-    g = Graph("te", tensor, breaks)
+    g = Graph("te", tensor, breaks, variants)
     g.embed("te.emb", a.vocab_size, a.te_dim)
     for i in range(a.te_conv_blocks):
         g.convnext(f"te.conv{i}", a.te_dim, a.te_hidden, a.te_kernel, 1)
@@ -152,7 +209,7 @@ def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=
         res = g.cur
         g.ln(f"te.sa{i}.ffn_ln", a.te_dim)
         g.linear(f"te.sa{i}.ffn1", a.te_ffn, a.te_dim)
-        g.plain("Gelu")
+        g.gelu()
         g.linear(f"te.sa{i}.ffn2", a.te_dim, a.te_ffn)
         g.cur = g.op("Add", [res, g.cur])
     for i in range(a.te_style_blocks):
@@ -161,7 +218,7 @@ def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=
     g.linear("te.proj", a.te_out_dim, a.te_dim)
     graphs["te"] = g
 
-    g = Graph("ve", tensor, breaks)
+    g = Graph("ve", tensor, breaks, variants)
     g.linear("ve.in", a.ve_dim, D)
     x = g.cur
     t = g.op("Concat", [g.op("Sin", ["current_step"]), g.op("Cos", ["current_step"])])
@@ -183,7 +240,7 @@ def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=
     g.linear("ve.out", D, a.ve_dim)
     graphs["ve"] = g
 
-    g = Graph("vo", tensor, breaks)
+    g = Graph("vo", tensor, breaks, variants)
     k = a.vo_in_kernel
     g.cur = g.op("Conv", [g.cur, g.init("vo.in", g.w("vo.in.w", (a.vo_dim, a.latent_dim, k))), g.init("vo.in", g.w("vo.in.b", (a.vo_dim,)))],
                  [ow.attr_ints("kernel_shape", [k]), ow.attr_ints("pads", [k // 2] * 2)])

@@ -2,7 +2,7 @@
 Only the protobuf wire format is used: ModelProto{ir_version=1, producer_name=2, graph=7},
 GraphProto{node=1, name=2, initializer=5, input=11, output=12}, TensorProto{dims=1, data_type=2, float_data=4,
 int64_data=7, name=8, raw_data=9}, NodeProto{input=1, output=2, name=3, op_type=4, attribute=5},
-AttributeProto{name=1, i=3, t=5, ints=8, type=20}."""
+AttributeProto{name=1, i=3, s=4, t=5, ints=8, type=20}."""
 import struct
 
 import numpy as np
@@ -60,6 +60,10 @@ def attr_ints(name, vs, packed=True):
     else:
         body += b"".join(_key(8, 0) + _varint(int(v)) for v in vs)
     return body + _key(20, 0) + _varint(7)  # type INTS
+
+
+def attr_str(name, v):
+    return _ld(1, name.encode()) + _ld(4, v.encode()) + _key(20, 0) + _varint(3)  # type STRING
 
 
 def attr_tensor(name, tensor_body):

@@ -250,3 +250,73 @@ def test_fold_dwconv_ln_vs_numpy(eng, k, dil, C):
         assert np.array_equal(xo, rxo)  # the fold is elementwise fp32 in a fixed order: exact
         mx, rms = rel_err(y, ry)
         assert rms < 4e-3 and mx < 4e-2, (mx, rms)  # one bf16 rounding of the normalised output (2^-9 of values up to ~5 sigma)
+
+
+# ---- the fused forms INSIDE the engine: stage-ordered weight packing, FfnArgs wiring, fold state, every stage mask ----
+
+def _mid_arch():
+    """A small stack whose ConvNeXt widths are the ones K4 supports (384 / 512), so that stn_set_fused_ffn_min_rows(1, 1) puts every
+    stage on the fused kernels with a handful of rows: text encoder 384/768 (mask 4), estimator 384/1536 (masks 2 and 8), vocoder
+    512/1024 (mask 1)."""
+    a = tiny_arch()
+    a.te_dim, a.te_hidden, a.te_heads, a.te_ffn, a.te_conv_blocks, a.te_attn_blocks = 384, 768, 4, 256, 2, 1
+    a.ve_dim, a.ve_hidden, a.ve_heads, a.ve_main_blocks, a.ve_dilated, a.ve_tail_blocks = 384, 1536, 4, 1, 3, 2
+    a.vo_dim, a.vo_hidden, a.vo_blocks = 512, 1024, 2
+    return a
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_engine_stages_with_every_fused_form_on_and_off_against_the_oracle(mode):
+    from oracle.neural_ref import RefModel, randn
+    from gpu_util import make_inputs, parity_check
+    a = _mid_arch()
+    ref = RefModel(a, 5)
+    ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5], seed=8)
+    durs = np.array([0.42, 0.30, 0.12], np.float32)
+    nz = {}
+
+    def nf(B, D, L):
+        nz["x"] = randn(77, B, D, L)
+        return nz["x"]
+
+    rw, rd = ref.synthesize(ids, mask, sttl, sdp, 2, 1.05, nf, duration_override=durs)
+    eng = binding.Engine(0, mode)
+    eng.load_synthetic(a, 5)
+    eng.set_fused_ffn_min_rows(1, 1)
+    out = {}
+    for packed in (True, False):
+        eng.set_packed_rows(packed)
+        for mask_bits in (0, 1, 2, 4, 7, 8, 15):
+            eng.set_fused_ffn(mask_bits)
+            w, d = eng.synthesize(ids, mask, sttl, sdp, 2, 1.05, noise=nz["x"], duration_override=durs)
+            np.testing.assert_allclose(d, rd, rtol=1e-6)
+            parity_check("ffn_forms.e2e_wav", mode, w, rw, "e2e")
+            out[(packed, mask_bits)] = w
+    # the forms differ from the two launches (and from each other) by rounding only, in both layouts
+    for key, w in out.items():
+        mx, rms = rel_err(w, out[(key[0], 0)])
+        assert mx < (2e-1 if mode == "bf16" else 3e-2) and rms < (3e-2 if mode == "bf16" else 5e-3), (key, mx, rms)
+    # K4-split exists in the packed layout only: in the padded one mask 8 changes nothing
+    assert np.array_equal(out[(False, 8)], out[(False, 0)]) and not np.array_equal(out[(True, 8)], out[(True, 0)])
+    assert not np.array_equal(out[(True, 2)], out[(True, 0)]) and not np.array_equal(out[(True, 4)], out[(True, 0)])
+    eng.close()
+
+
+def test_k4_split_graph_replay_is_bit_identical_to_eager():
+    from gpu_util import make_inputs
+    a = _mid_arch()
+    eng = binding.Engine(0, "bf16")
+    eng.load_synthetic(a, 5)
+    eng.set_fused_ffn_min_rows(1, 1)
+    eng.set_fused_ffn(15)
+    ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5], seed=8)
+    durs = np.array([0.42, 0.30, 0.12], np.float32)
+    eng.set_graph_mode(False)
+    w0, _ = eng.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=3)
+    eng.set_graph_mode(True)
+    r0 = eng.graph_replays
+    for _ in range(4):
+        w, _ = eng.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=3)
+        assert np.array_equal(w, w0)
+    assert eng.graph_replays >= r0 + 2
+    eng.close()

@@ -63,12 +63,73 @@ def test_estimator_without_dilated_blocks_or_tail(tmp_path):
     assert (got["ve_dilated"], got["ve_tail_blocks"], got["ve_main_blocks"]) == (0, 0, 3)
 
 
-def test_heads_missing_from_the_graph_are_reported_not_guessed(tmp_path):
+def test_heads_missing_from_the_graph_are_an_error_until_stated(tmp_path):
+    """No weight shape shows a head count: a graph without the [batch, length, heads, head_dim] Reshape constants does not load on a
+    guess; a stn_weight_map.json WITHOUT a "tensors" table states the three counts and the walk proceeds."""
+    import json
     a = tiny_arch()
     build_graph_dir(tmp_path, a, _zeros(a), with_heads=False)
+    with pytest.raises(OSError, match=r"dp_heads is not readable from the graph.*stn_weight_map\.json"):
+        host.bind_graphs(str(tmp_path))
+    (tmp_path / "stn_weight_map.json").write_text(json.dumps({"arch": {"dp_heads": a.dp_heads, "te_heads": a.te_heads, "ve_heads": a.ve_heads}}))
     got = host.bind_graphs(str(tmp_path))
     for f in ("te_heads", "dp_heads", "ve_heads"):
-        assert f in got["notes"]
+        assert got["arch"][f] == getattr(a, f) and f + " = " in got["notes"]
+    (tmp_path / "stn_weight_map.json").write_text(json.dumps({"arch": {"dp_heads": 2, "te_heads": 2, "ve_heads": 5}}))
+    with pytest.raises(OSError, match=r"ve_heads = 5 \(stated in stn_weight_map\.json\) does not divide the width 96"):
+        host.bind_graphs(str(tmp_path))
+    (tmp_path / "stn_weight_map.json").write_text(json.dumps({"arch": {"ve_dim": 128}}))
+    with pytest.raises(OSError, match=r"may state only the head counts"):
+        host.bind_graphs(str(tmp_path))
+
+
+VARIANTS = [dict(ln="decomposed"), dict(ln="decomposed_nobeta"), dict(qkv="fused"), dict(pw="matmul_transpose"), dict(gelu="erf"), dict(gelu="tanh"),
+            dict(gelu="op_tanh"), dict(ln="decomposed", qkv="fused", pw="matmul_transpose", gelu="erf")]
+
+
+@pytest.mark.parametrize("variants", VARIANTS, ids=lambda v: "+".join(f"{k}={x}" for k, x in v.items()))
+def test_exporter_variants_of_the_layout_bind_to_the_same_tensors(tmp_path, variants):
+    """LayerNorm decomposed into ReduceMean / Sub / Pow / Sqrt / Div / Mul / Add, q|k|v (k|v) as one fused
+    projection + Split, pointwise convolutions as Transpose -> MatMul -> Add -> Transpose, GELU spelled with Erf or Tanh: the same
+    descriptor, every canonical tensor bound to the same VALUES as from the plain graphs."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    plain = tmp_path / "plain"
+    var = tmp_path / "variant"
+    plain.mkdir(); var.mkdir()
+    build_graph_dir(plain, a, ref.tensor)
+    build_graph_dir(var, a, ref.tensor, variants=variants)
+    g0, g1 = host.bind_graphs(str(plain)), host.bind_graphs(str(var))
+    for f in ARCH_FIELDS:
+        assert g1["arch"][f] == getattr(a, f), f
+    assert set(g1["tensors"]) == set(ref.tensor_names())
+    zeros = sorted(n for n, e in g1["tensors"].items() if e["zeros"])
+    if variants.get("ln") == "decomposed_nobeta":
+        assert zeros and all(n.endswith("ln.b") or n.endswith("_ln.b") for n in zeros)
+    else:
+        assert not zeros
+    if variants.get("qkv") == "fused":
+        fused = {n: e for n, e in g1["tensors"].items() if e["rows_total"]}
+        assert {"te.sa0.q.w", "te.sa0.k.w", "te.sa0.v.b", "ve.m0.text.k.w", "ve.m0.text.v.w", "dp.st.k.b"} <= set(fused)
+        assert g1["tensors"]["te.sa0.k.w"]["row0"] == a.te_dim and g1["tensors"]["te.sa0.v.w"]["rows_total"] == 3 * a.te_dim
+        assert g1["tensors"]["ve.m0.style.v.w"]["row0"] == a.ve_dim and g1["tensors"]["ve.m0.style.v.w"]["rows_total"] == 2 * a.ve_dim
+        assert "ve.m0.text.q.w" not in fused
+    want_gelu = {"erf": "erf", "tanh": "tanh", "op_tanh": "tanh"}.get(variants.get("gelu"), "op")
+    assert g1["gelu"] == want_gelu and g0["gelu"] == "op"
+    assert ("Tanh" in g1["notes"]) == (want_gelu == "tanh")
+    if variants.get("ln", "").startswith("decomposed"):
+        assert "decomposed LayerNormalization" in g1["tensors"]["vo.out_ln.g"]["from"]
+
+
+def test_variant_values_reach_the_engine_layout(tmp_path):
+    """The values behind the bindings, host side: stn_bound_tensor fetches a canonical tensor as the engine would load it (transposed /
+    sliced out of a fused projection / zero-filled) — equal to the oracle's tensor for every name, in the all-variants graph."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    build_graph_dir(tmp_path, a, ref.tensor, variants=dict(ln="decomposed", qkv="fused", pw="matmul_transpose", gelu="tanh"))
+    for name in ref.tensor_names():
+        got = host.bound_tensor(str(tmp_path), name)
+        np.testing.assert_array_equal(got, ref.tensor(name), err_msg=name)
 
 
 @pytest.mark.parametrize("breaks,needle", [
