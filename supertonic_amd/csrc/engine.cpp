@@ -558,11 +558,11 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     // for 128 rows is ingest-bound): four workgroups per slab, each over a quarter of the hidden units (a quarter of the weight
     // stream), 16-bit partial sums; b2, layer scale, residual and time vector are applied by the next reader of x.  The split is a
     // function of the block's shape only.  Packed rows only (the fold kernels index sequences through row_off).
-    if (fs && rg && (fused_ffn_ & 8) && stage_bit == 2 && fw != ffn_w_.end() && fw->second.wsplit && M >= ffn_split_min_rows_ &&
+    if (fs && fs->S > 1 && rg && (fused_ffn_ & 8) && stage_bit == 2 && fw != ffn_w_.end() && fw->second.wsplit[split_slot(fs->S)] && M >= ffn_split_min_rows_ &&
         M * C * 2 < 0x7FFFFFFFll && fold_dwconv_ln_supported(C, k, 1 << std::max(0, a_.ve_dilated - 1))) {
         FfnArgs fa;
-        fa.xn = xn; fa.ldx = C; fa.wseq = fw->second.wsplit; fa.b1 = p.pw1.b; fa.M = (int)M; fa.I = hid;
-        fa.split = fw->second.S; fa.part = fs->part; fa.part_stride = fs->part_stride;
+        fa.xn = xn; fa.ldx = C; fa.wseq = fw->second.wsplit[split_slot(fs->S)]; fa.b1 = p.pw1.b; fa.M = (int)M; fa.I = hid;
+        fa.split = fs->S; fa.part = fs->part; fa.part_stride = fs->part_stride;
         if (prof_on_) prof_begin("ffn_split", 4.0 * M * (double)C * hid, (double)M * C * (2.0 + 2.0 * fa.split) + 4.0 * C * hid);
         launch_ffn_fused(s_, dt_, C, fa);
         if (prof_on_) prof_end();
@@ -812,11 +812,12 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     FoldState fs;  // the residual stream (and, with K4-split blocks, its pending update)
     fs.x = f32_alloc(M * C);
     {
-        const int S = ffn_split_factor(dt_, C, a.ve_hidden);
+        const int S = ffn_split_choose(dt_, C, a.ve_hidden, M);
         if (rg && S > 1 && (fused_ffn_ & 8) && M >= ffn_split_min_rows_) {
             fs.x_alt = f32_alloc(M * C);
             fs.part_stride = ffn_split_rows(M) * C;
             fs.part = act_alloc(fs.part_stride * S);
+            fs.S = S;
         }
     }
     FoldState* const fsp = fs.part ? &fs : nullptr;
@@ -912,15 +913,16 @@ void Engine::prepare_ffn_weights() {
         launch_ffn_pack(s_, c.pw1.w.as(dt_), c.pw2.w.as(dt_), C, hid, tmp, wseq);
         sync();  // tmp is reused by the next block
         FfnW fw; fw.wseq = wseq;
-        const int S = p.compare(0, 3, "ve.") == 0 ? ffn_split_factor(dt_, C, hid) : 0;  // the estimator's blocks also as hidden-split streams
-        if (S > 1) {
-            void* ws = nullptr;
-            STN_HIP(hipMalloc(&ws, (size_t)2 * hid * C * 2));
-            owned_.push_back(ws);
-            launch_ffn_pack(s_, c.pw1.w.as(dt_), c.pw2.w.as(dt_), C, hid, tmp, ws, S);
-            sync();
-            fw.wsplit = ws; fw.S = S;
-        }
+        if (p.compare(0, 3, "ve.") == 0)  // the estimator's blocks also as hidden-split stage streams, one copy per split
+            for (int S : {4, 12}) {  // (the splits ffn_split_choose hands out)
+                if (!ffn_split_valid(dt_, C, hid, S)) continue;
+                void* ws = nullptr;
+                STN_HIP(hipMalloc(&ws, (size_t)2 * hid * C * 2));
+                owned_.push_back(ws);
+                launch_ffn_pack(s_, c.pw1.w.as(dt_), c.pw2.w.as(dt_), C, hid, tmp, ws, S);
+                sync();
+                fw.wsplit[split_slot(S)] = ws;
+            }
         ffn_w_[c.pw1.w.as(dt_)] = fw;
     };
     auto S = [](const char* fmt, int i, int j = 0) { char b[64]; snprintf(b, sizeof b, fmt, i, j); return std::string(b); };
@@ -1726,7 +1728,7 @@ void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const
     if (fused) {
         void* tmp = act_alloc((int64_t)2 * I * C);
         void* wseq = act_alloc((int64_t)2 * I * C);
-        const int S = mode == 2 ? ffn_split_factor(dt_, C, I) : 1;
+        const int S = mode == 2 ? ffn_split_choose(dt_, C, I, M) : 1;
         launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
         FfnArgs fa;
         fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
@@ -1761,7 +1763,7 @@ void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const
 void Engine::op_ffn_bench(int M, int C, int I, int mode, int iters, double* out5) {
     STN_HIP(hipSetDevice(device_));
     const bool fused = mode != 0;
-    const int S = mode == 2 ? ffn_split_factor(dt_, C, I) : 1;
+    const int S = mode == 2 ? ffn_split_choose(dt_, C, I, M) : 1;
     if (mode == 2 && S < 2) throw std::invalid_argument("op_ffn_bench: shape not supported by the hidden-split kernel");
     if (!is_half(dt_)) throw std::invalid_argument("op_ffn_bench: 16-bit engines only");
     if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn_bench: shape not supported by the fused kernel");
@@ -1888,7 +1890,7 @@ void Engine::op_fold_dwconv_ln(int B, int C, int k, int dil, int S, const int* s
 void Engine::op_block_bench(int B, int L, int C, int I, int k, int dil, int mode, int iters, double* out2) {
     STN_HIP(hipSetDevice(device_));
     if (!is_half(dt_)) throw std::invalid_argument("op_block_bench: 16-bit engines only");
-    const int S = ffn_split_factor(dt_, C, I);
+    const int S = ffn_split_choose(dt_, C, I, (int64_t)B * L);
     if (mode == 2 && S < 2) throw std::invalid_argument("op_block_bench: shape not supported by the hidden-split kernel");
     ar_.reset();
     for (int i = 0; i < 6; ++i) out2[i] = 0.0;

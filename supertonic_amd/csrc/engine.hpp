@@ -116,7 +116,8 @@ class Engine {
     int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
     void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
-    struct FfnW { const void* wseq = nullptr; const void* wsplit = nullptr; int S = 0; };  // wsplit: the hidden-split stage streams (S = ffn_split_factor)
+    struct FfnW { const void* wseq = nullptr; const void* wsplit[3] = {nullptr, nullptr, nullptr}; };  // wsplit: the hidden-split stage streams for S = 4, 12, 24
+    static int split_slot(int S) { return S == 4 ? 0 : S == 12 ? 1 : 2; }
     std::unordered_map<const void*, FfnW> ffn_w_;  // key: the block's row-major 16-bit pw1 matrix
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------
@@ -271,6 +272,7 @@ class Engine {
         float* x_alt = nullptr;  // second buffer: fold_dwconv_ln writes the folded stream there and the two swap
         void* part = nullptr;    // [S][rows padded to 128][C] 16-bit partial sums (one buffer: its reader runs before the next writer)
         int64_t part_stride = 0;
+        int S = 0;               // the split this stage's launches take (ffn_split_choose of its row count)
         bool pending = false;
         FoldArgs fold;           // the pending update
     };
@@ -344,7 +346,7 @@ class Engine {
     bool copied_valid_ = false;
     int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
-    int64_t ffn_split_min_rows_ = 4096;  // K4-split only from this many rows on; STN_FFN_SPLIT_MIN_ROWS overrides
+    int64_t ffn_split_min_rows_ = 100;   // K4-split only from this many rows on (one utterance ties with the three launches); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines

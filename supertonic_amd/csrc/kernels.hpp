@@ -135,6 +135,9 @@ bool ffn_fused_supported(int dtype, int C, int I);
 // hidden-split factor of the K4-split form for this block shape (0: not supported).  A function of (C, I) ONLY: a row's result
 // must not depend on the number of rows in the launch.
 int ffn_split_factor(int dtype, int C, int I);
+// splits a block shape can run with (4, 12, 24: I / 32 / S hidden tiles per workgroup, an even number), and the one a launch of M rows takes
+bool ffn_split_valid(int dtype, int C, int I, int S);
+int ffn_split_choose(int dtype, int C, int I, int64_t M);
 inline int64_t ffn_split_rows(int64_t M) { return (M + 127) / 128 * 128; }
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a);
 // The pending update of a K4-split launch, folded by the next reader of x:

@@ -200,6 +200,24 @@ int ffn_split_factor(int dtype, int C, int I) {
     if (!ffn_fused_supported(dtype, C, I) || C != 384 || I < 1024 || (I / 32) % 8) return 0;
     return 4;
 }
+bool ffn_split_valid(int dtype, int C, int I, int S) {
+    return ffn_split_factor(dtype, C, I) > 1 && (S == 4 || S == 12 || S == 24) && (I / 32) % (2 * S) == 0;
+}
+// Few rows: more, shorter workgroups per slab (each still streams only ITS share of the weights, so the cost of a launch is one
+// workgroup's prologue + its T = I/32/S hidden tiles + epilogue, whatever the number of slabs).  Measured on B sequences of 58 frames
+// (tools/ffn_bench.py splitm, profiles/r03_ffn_split_small_m.txt; block = conv kernel + pointwise pair, us): 2..32 sequences
+// (116..1856 rows) 12 ways 23-28 against 4 ways 28-31 and three launches 29-33; from 48 sequences on 4 ways wins (32 against 39
+// and 40); 24 ways never did (its fold reads 24 partial sums per element), and ONE sequence ties with the three launches (20.9 /
+// 21.2) — the launch is then a chain of fixed latencies (6 k cycles of prologue, 4 k of epilogue) around 12 k cycles of work.
+// Which split a launch takes depends on its row count: results of different splits agree to rounding (16-bit partial sums), not
+// bit for bit (include/stn.h).
+int ffn_split_choose(int dtype, int C, int I, int64_t M) {
+    if (ffn_split_factor(dtype, C, I) < 2) return 0;
+    static const int force = [] { const char* e = getenv("STN_FFN_SPLIT_S"); return e ? atoi(e) : 0; }();  // A/B switch
+    const int64_t nslab = (M + 127) / 128;
+    const int want = force ? force : nslab <= 16 ? 12 : 4;
+    return ffn_split_valid(dtype, C, I, want) ? want : 4;
+}
 
 template <int C>
 static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
@@ -236,9 +254,9 @@ static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a) {
     if (a.M <= 0) return;
     if (!ffn_fused_supported(dtype, C, a.I)) throw std::invalid_argument("launch_ffn_fused: unsupported shape or dtype");
-    if (a.split > 1 && (a.split != ffn_split_factor(dtype, C, a.I) || !a.part || a.part_stride < ffn_split_rows(a.M) * C ||
+    if (a.split > 1 && (!ffn_split_valid(dtype, C, a.I, a.split) || !a.part || a.part_stride < ffn_split_rows(a.M) * C ||
                         (reinterpret_cast<uintptr_t>(a.part) & 15)))
-        throw std::invalid_argument("launch_ffn_fused: hidden split needs split == ffn_split_factor(C, I) and a 16-byte aligned part buffer of [split][rows padded to 128][C]");
+        throw std::invalid_argument("launch_ffn_fused: hidden split needs a valid split (4, 12 or 24 dividing I / 64) and a 16-byte aligned part buffer of [split][rows padded to 128][C]");
     if (a.split <= 1 && a.part) throw std::invalid_argument("launch_ffn_fused: part without split");
     if ((size_t)a.M * a.ldx * 2 >= 0x7FFFFFFFull || a.ldx % 8 || (reinterpret_cast<uintptr_t>(a.xn) & 15) ||
         (a.split <= 1 && (a.ldo % 4 || !a.x || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.rowvec && (a.rv_ld % 4 || (reinterpret_cast<uintptr_t>(a.rowvec) & 15))))))

@@ -448,21 +448,40 @@ void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, i
 // branch around every load and wait for each one in turn: cdna_hip_programming.md, Projection GEMM item 4(c)); the optional
 // time vector is a template parameter, the split count a compile-time constant.
 // ---------------------------------------------------------------------------------------------
-static constexpr int FOLD_S = 4;  // splits a fold accepts (= ffn_split_factor of the estimator's block)
+// Splits a fold accepts: ffn_split_choose's values (kernels_ffn.hip).  The partial sums are added in split order, one after the other.
 template <bool F16>
 __device__ __forceinline__ float p16_to_f(unsigned h) {  // one 16-bit partial (low 16 bits of h) -> fp32
     if constexpr (F16) { const _Float16 v = __builtin_bit_cast(_Float16, (uint16_t)h); return (float)v; }
     else return __uint_as_float(h << 16);
 }
-// N consecutive channels of one row: w[sp][j] holds channels 2j, 2j+1 of split sp
-template <bool F16, int N>
-__device__ __forceinline__ void fold_sum(const unsigned (&w)[FOLD_S][N / 2], float (&acc)[N]) {
+// acc[0..N) (+)= the N consecutive channels at `p16` of splits [s0, s0 + CH): CH loads of N * 2 bytes issued together, then added
+// in split order.  FIRST: acc starts from split s0 instead of being added to.
+template <bool F16, int N, int CH, bool FIRST>
+__device__ __forceinline__ void fold_chunk(const uint16_t* __restrict__ p16, int64_t pstride, int s0, float (&acc)[N]) {
+    unsigned w[CH][N / 2];
 #pragma unroll
-    for (int j = 0; j < N / 2; ++j) { acc[2 * j] = p16_to_f<F16>(w[0][j] & 0xFFFFu); acc[2 * j + 1] = p16_to_f<F16>(w[0][j] >> 16); }
+    for (int c = 0; c < CH; ++c) {
+        const uint16_t* q = p16 + (size_t)(s0 + c) * pstride;
+        if constexpr (N == 8) { const uint4 u = *reinterpret_cast<const uint4*>(q); w[c][0] = u.x; w[c][1] = u.y; w[c][2] = u.z; w[c][3] = u.w; }
+        else { const uint2 u = *reinterpret_cast<const uint2*>(q); w[c][0] = u.x; w[c][1] = u.y; }
+    }
 #pragma unroll
-    for (int sp = 1; sp < FOLD_S; ++sp)
+    for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int j = 0; j < N / 2; ++j) { acc[2 * j] += p16_to_f<F16>(w[sp][j] & 0xFFFFu); acc[2 * j + 1] += p16_to_f<F16>(w[sp][j] >> 16); }
+        for (int j = 0; j < N / 2; ++j) {
+            const float lo = p16_to_f<F16>(w[c][j] & 0xFFFFu), hi = p16_to_f<F16>(w[c][j] >> 16);
+            if (FIRST && c == 0) { acc[2 * j] = lo; acc[2 * j + 1] = hi; }
+            else { acc[2 * j] += lo; acc[2 * j + 1] += hi; }
+        }
+}
+// the whole sum over S splits, in chunks of at most 12 loads in flight
+template <bool F16, int N, int S>
+__device__ __forceinline__ void fold_sum(const uint16_t* __restrict__ p16, int64_t pstride, float (&acc)[N]) {
+    constexpr int CH = S <= 12 ? S : 12;
+    static_assert(S % CH == 0, "split count");
+    fold_chunk<F16, N, CH, true>(p16, pstride, 0, acc);
+#pragma unroll
+    for (int s0 = CH; s0 < S; s0 += CH) fold_chunk<F16, N, CH, false>(p16, pstride, s0, acc);
 }
 __device__ __forceinline__ float fold_one(float x, float y, float b2, float gm, float rv) { return x + gm * (y + b2) + rv; }
 __device__ __forceinline__ float4 fold_four(float4 x, const float* acc, float4 b2, float4 gm, float4 rv) {
@@ -471,7 +490,7 @@ __device__ __forceinline__ float4 fold_four(float4 x, const float* acc, float4 b
 }
 
 // fold + LayerNorm, one wavefront per row (rows are independent: x is updated in place)
-template <typename OutT, bool F16, bool RV>
+template <typename OutT, bool F16, bool RV, int S>
 __global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ x, int64_t M, int C, const uint16_t* __restrict__ part,
                                                       int64_t pstride, const float* __restrict__ b2, const float* __restrict__ gamma,
                                                       const float* __restrict__ rowvec, int rv_ld, const int* __restrict__ row_b,
@@ -492,17 +511,11 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ x, int
         h[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c4 < C4) {
             const float4 xo = x4[c4];
-            unsigned w[FOLD_S][2];
-#pragma unroll
-            for (int sp = 0; sp < FOLD_S; ++sp) {
-                const uint2 u = *reinterpret_cast<const uint2*>(part + (size_t)sp * pstride + (size_t)row * C + c4 * 4);
-                w[sp][0] = u.x; w[sp][1] = u.y;
-            }
             const float4 bb = b24[c4], gm = gm4[c4];
             float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (RV) tv = rv4[c4];
             float acc[4];
-            fold_sum<F16, 4>(w, acc);
+            fold_sum<F16, 4, S>(part + (size_t)row * C + c4 * 4, pstride, acc);
             h[i] = fold_four(xo, acc, bb, gm, tv);
             x4[c4] = h[i];
         }
@@ -533,9 +546,9 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ x, int
 }
 
 static void check_fold_args(const FoldArgs& f, int64_t M, int C, const char* who) {
-    if (!f.part || f.S != FOLD_S || f.part_stride < M * C || !f.b2 || !f.gamma || (f.rowvec && f.rv_ld % 4) || (reinterpret_cast<uintptr_t>(f.part) & 15) ||
+    if (!f.part || (f.S != 4 && f.S != 12 && f.S != 24) || f.part_stride < M * C || !f.b2 || !f.gamma || (f.rowvec && f.rv_ld % 4) || (reinterpret_cast<uintptr_t>(f.part) & 15) ||
         (reinterpret_cast<uintptr_t>(f.b2) & 15) || (reinterpret_cast<uintptr_t>(f.gamma) & 15) || (f.rowvec && (reinterpret_cast<uintptr_t>(f.rowvec) & 15)))
-        throw std::invalid_argument(std::string(who) + ": needs 16-byte aligned partial sums of exactly 4 splits, b2 and gamma");
+        throw std::invalid_argument(std::string(who) + ": needs 16-byte aligned partial sums of 4, 12 or 24 splits, b2 and gamma");
 }
 
 void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, const FoldArgs& f, const float* g, const float* b, float eps, void* y) {
@@ -545,10 +558,12 @@ void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, co
     check_fold_args(f, M, C, "launch_fold_ln");
     const dim3 grid((unsigned)((M + 3) / 4));
     const uint16_t* P = static_cast<const uint16_t*>(f.part);
-#define STN_FOLD_LN(OUT, F16_, RV_) STN_KLAUNCH((fold_ln_kernel<OUT, F16_, RV_>), grid, dim3(256), 0, s, x, M, C, P, f.part_stride, f.b2, f.gamma, f.rowvec, \
-                                                f.rv_ld, f.row_b, g, b, eps, static_cast<OUT*>(y))
-    if (act_dtype == F16) { if (f.rowvec) STN_FOLD_LN(f16_t, true, true); else STN_FOLD_LN(f16_t, true, false); }
-    else { if (f.rowvec) STN_FOLD_LN(uint16_t, false, true); else STN_FOLD_LN(uint16_t, false, false); }
+#define STN_FOLD_LN(OUT, F16_, RV_, S_) STN_KLAUNCH((fold_ln_kernel<OUT, F16_, RV_, S_>), grid, dim3(256), 0, s, x, M, C, P, f.part_stride, f.b2, f.gamma, f.rowvec, \
+                                                    f.rv_ld, f.row_b, g, b, eps, static_cast<OUT*>(y))
+#define STN_FOLD_LN_S(OUT, F16_, RV_) do { if (f.S == 4) STN_FOLD_LN(OUT, F16_, RV_, 4); else if (f.S == 12) STN_FOLD_LN(OUT, F16_, RV_, 12); else STN_FOLD_LN(OUT, F16_, RV_, 24); } while (0)
+    if (act_dtype == F16) { if (f.rowvec) STN_FOLD_LN_S(f16_t, true, true); else STN_FOLD_LN_S(f16_t, true, false); }
+    else { if (f.rowvec) STN_FOLD_LN_S(uint16_t, false, true); else STN_FOLD_LN_S(uint16_t, false, false); }
+#undef STN_FOLD_LN_S
 #undef STN_FOLD_LN
 }
 
@@ -562,7 +577,7 @@ void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, co
 // behind the barrier), nothing is stored to global memory before the barrier (a store in flight would be waited for there), and
 // the x_out stores are the last thing a thread issues.
 static constexpr int FOLD_TCH = 32, FOLD_NT = 1024;  // FOLD_TCH == 2 * wavefronts per workgroup
-template <typename OutT, bool F16, int K, bool RV, int FOLD_NSLOT /* float4 slots per lane of a half wavefront: ceil(C / 128) */>
+template <typename OutT, bool F16, int K, bool RV, int FOLD_NSLOT /* float4 slots per lane of a half wavefront: ceil(C / 128) */, int S>
 __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __restrict__ xin, float* __restrict__ xout, int cps, int C,
                                                                  const uint16_t* __restrict__ part, int64_t pstride,
                                                                  const float* __restrict__ b2, const float* __restrict__ gamma,
@@ -599,7 +614,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     }
     // ---- phase 1: a thread keeps ONE 8-channel group (its b2 / gamma / time-vector values are loaded once) and walks down the
     // window rows, `rpp` rows apart; every load of U rows is issued before the first use ----
-    constexpr int U = 2;
+    constexpr int U = S <= 4 ? 2 : 1;  // (more splits: one row at a time, the partial sums in chunks of 12 loads)
     const int rpp = FOLD_NT / C8;  // rows per pass of the workgroup
     const int c8 = tid % C8, rq = tid / C8;
     if (rq < rpp) {
@@ -610,28 +625,45 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
         if constexpr (RV) { const float4* tp = reinterpret_cast<const float4*>(rowvec + (size_t)b * rv_ld + c8 * 8); tv0 = tp[0]; tv1 = tp[1]; }
         for (int r0 = rq; r0 < nw; r0 += rpp * U) {
             float4 xa[U][2];
-            unsigned w[U][FOLD_S][4];
+            float acc[U][8];
+            int64_t mrow[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = min(r0 + u * rpp, nw - 1);  // (past the end: the last row again, stored nowhere)
-                const int64_t m = row0 + w0 + r;
-                const float4* xp = reinterpret_cast<const float4*>(xin + m * C + c8 * 8);
+                mrow[u] = row0 + w0 + r;
+                const float4* xp = reinterpret_cast<const float4*>(xin + mrow[u] * C + c8 * 8);
                 xa[u][0] = xp[0]; xa[u][1] = xp[1];
+            }
+            if constexpr (U == 2) {  // every load of both rows is issued before the first use
+                constexpr int CH = S;
+                unsigned w[2][CH][4];
 #pragma unroll
-                for (int sp = 0; sp < FOLD_S; ++sp) {
-                    const uint4 q = *reinterpret_cast<const uint4*>(part + (size_t)sp * pstride + (size_t)m * C + c8 * 8);
-                    w[u][sp][0] = q.x; w[u][sp][1] = q.y; w[u][sp][2] = q.z; w[u][sp][3] = q.w;
-                }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int sp = 0; sp < CH; ++sp) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(part + (size_t)sp * pstride + (size_t)mrow[u] * C + c8 * 8);
+                        w[u][sp][0] = q.x; w[u][sp][1] = q.y; w[u][sp][2] = q.z; w[u][sp][3] = q.w;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int sp = 0; sp < CH; ++sp)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = p16_to_f<F16>(w[u][sp][j] & 0xFFFFu), hi = p16_to_f<F16>(w[u][sp][j] >> 16);
+                            if (sp == 0) { acc[u][2 * j] = lo; acc[u][2 * j + 1] = hi; }
+                            else { acc[u][2 * j] += lo; acc[u][2 * j + 1] += hi; }
+                        }
+            } else {
+                fold_sum<F16, 8, S>(part + (size_t)mrow[0] * C + c8 * 8, pstride, acc[0]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                float acc[8];
-                fold_sum<F16, 8>(w[u], acc);
                 const int r = r0 + u * rpp;
                 if (r < nw) {
                     float4* sp4 = reinterpret_cast<float4*>(fold_sm + (size_t)r * C + c8 * 8);
-                    sp4[0] = fold_four(xa[u][0], acc, bb0, gm0, tv0);
-                    sp4[1] = fold_four(xa[u][1], acc + 4, bb1, gm1, tv1);
+                    sp4[0] = fold_four(xa[u][0], acc[u], bb0, gm0, tv0);
+                    sp4[1] = fold_four(xa[u][1], acc[u] + 4, bb1, gm1, tv1);
                 }
             }
         }
@@ -712,16 +744,23 @@ bool fold_dwconv_ln_supported(int C, int k, int dil) {
     return C % 8 == 0 && C <= 512 && (k == 5 || k == 7) && dil >= 1 && fold_dwconv_lds(C, k, dil) <= 160 * 1024;
 }
 
-template <typename OutT, bool F16, int K, bool RV, int NSLOT>
-static void launch_fold_dwconv_ln_t2(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
+template <typename OutT, bool F16, int K, bool RV, int NSLOT, int S>
+static void launch_fold_dwconv_ln_t3(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
                                      const float* bias, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen, const int* row_off) {
     static PerDeviceOnce attr_once;
     if (attr_once.need())
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024), "hipFuncSetAttribute(fold_dwconv_ln)");
     const int cps = (L + FOLD_TCH - 1) / FOLD_TCH;
-    STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil), s, x_in, x_out, cps, C,
+    STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil), s, x_in, x_out, cps, C,
                 static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, 1.0f / (float)C, y, seqlen, row_off, f.ts);
+}
+template <typename OutT, bool F16, int K, bool RV, int NSLOT>
+static void launch_fold_dwconv_ln_t2(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
+                                     const float* bias, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen, const int* row_off) {
+    if (f.S == 4) launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 4>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+    else if (f.S == 12) launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 12>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+    else launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 24>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
 }
 template <typename OutT, bool F16, int K, bool RV>
 static void launch_fold_dwconv_ln_t(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,

@@ -127,6 +127,9 @@ def test_trimmed_dense_vocoder_is_bit_identical(dtype16):
     a = default_arch()
     eng = binding.Engine(0, dtype16)
     eng.load_synthetic(a, 7)
+    # this test is about the VOCODER's two forms; the estimator's K4-split exists in the packed layout only (its fold kernels index
+    # sequences through the packed row map), so it is switched off here to keep both layouts on the same estimator kernels
+    eng.set_fused_ffn(1)
     rng = np.random.default_rng(3)
     for case in range(4):
         B = [6, 3, 12, 3][case]
@@ -160,6 +163,7 @@ def test_trimmed_dense_vocoder_boundary_paddings(dtype16):
     a = default_arch()
     eng = binding.Engine(0, dtype16)
     eng.load_synthetic(a, 7)
+    eng.set_fused_ffn(1)  # (as above: the same estimator kernels in both layouts)
     # latent lengths 60 (longest), 41 (19 latent = 114 vocoder frames of padding), 40 (120), 42 (108: dense), 10
     durs = np.array([4.17, 2.85, 2.78, 2.92, 0.69], np.float32)
     B, Lt = 5, 30

@@ -13,6 +13,15 @@ if what == "splitvar":  # one line for the timing-variants build (STN_LIB=build/
     best = min(f, key=lambda r: r["ms"])
     print(f"var={os.environ.get('STN_FFN_VAR', '0')} ve M=7436 K4-split {best['ms']*1e3:7.1f} us cycles/wg: first={best['first_stage']:.0f} loop={best['tile_loop']:.0f} epi={best['epilogue']:.0f}", flush=True)
     sys.exit(0)
+if what == "splitm":  # few rows: which split pays (STN_FFN_SPLIT_S=<4|12|24> forces one; unset: ffn_split_choose)
+    tag = os.environ.get("STN_FFN_SPLIT_S", "auto")
+    for B in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128):
+        a = min((eng.op_block_bench(B, 58, 384, 1536, 5, 2, 0, iters) for _ in range(2)), key=lambda r: r["ms"])
+        b = min((eng.op_block_bench(B, 58, 384, 1536, 5, 2, 2, iters) for _ in range(2)), key=lambda r: r["ms"])
+        k = min((eng.op_ffn_bench(B * 58, 384, 1536, 2, iters) for _ in range(2)), key=lambda r: r["ms"])
+        print(f"S={tag:4s} B={B:4d} rows={B*58:5d}: three launches {a['ms']*1e3:6.1f} us (dwconv_ln {a['conv_ms']*1e3:5.1f})   fold_dwconv_ln + K4-split {b['ms']*1e3:6.1f} us "
+              f"(fold {b['conv_ms']*1e3:5.1f}, K4-split {k['ms']*1e3:5.1f}: wgs={k['workgroups']} first={k['first_stage']:.0f} loop={k['tile_loop']:.0f} epi={k['epilogue']:.0f})", flush=True)
+    sys.exit(0)
 if what == "split":
     # the estimator's block: pointwise pair alone (two launches / K4-split), and the whole block chain with its conv kernel
     for M in (58, 464, 1024, 2048, 4096, 7436, 9984, 14872, 20000, 29744):
