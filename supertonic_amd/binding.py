@@ -98,6 +98,7 @@ def load():
     L.stn_set_graph_mode.argtypes = [vp, ci]
     L.stn_set_vocoder_mode.argtypes = [vp, ci]
     L.stn_set_row_layout.argtypes = [vp, ci]
+    L.stn_set_fused_xattn.argtypes = [vp, ci]
     L.stn_batch_ve_rows.argtypes = [vp]
     L.stn_batch_ve_rows.restype = ctypes.c_int64
     L.stn_batch_vo_rows.argtypes = [vp]
@@ -282,6 +283,10 @@ class Engine:
     def set_fused_ffn(self, mask):
         """K4 stage mask: 1 vocoder, 2 vector estimator, 4 text encoder / duration predictor (0 = two GEMM launches everywhere)."""
         self._ck(self._lib.stn_set_fused_ffn(self._h, int(mask)))
+
+    def set_fused_xattn(self, on=True):
+        """Cross-attention blocks of the vector estimator as one fused launch each or as four launches."""
+        self._ck(self._lib.stn_set_fused_xattn(self._h, int(bool(on))))
 
     @property
     def vo_rows(self):

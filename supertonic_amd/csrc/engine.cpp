@@ -116,6 +116,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
+    if (const char* p = getenv("STN_XATTN")) fused_xattn_ = atoi(p) != 0;  // A/B switch: one launch per cross-attention block
     if (const char* p = getenv("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
@@ -144,6 +145,7 @@ void Engine::free_weights() {
     for (void* p : owned_) (void)hipFree(p);
     owned_.clear();
     w_.clear();
+    frag_w_.clear();
     ffn_w_.clear();
     loaded_ = false;
     params_ = 0;
@@ -417,6 +419,7 @@ void Engine::load_weights(const stn_arch& a, const RawSource& src, std::vector<s
     decl_linear("vo.head", a.base_chunk_size, a.vo_dim, a.head_gain, false);
     if (!names_only) {
         loaded_ = true;
+        prepare_xattn_weights();
         prepare_ffn_weights();
         prepare_vocoder_constants();
     }
@@ -828,6 +831,19 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     auto cross = [&](const std::string& p, const void* kv_all, int blk, int Lk, const int* klen, int rope_mode) {
         // q from x, K/V precomputed (columns blk*2C .. of kv_all, row stride nb*2C)
         const Attn w = attn_w(p, false);
+        const char* kp0 = static_cast<const char*>(kv_all) + (size_t)blk * 2 * C * esz;
+        const auto fq = frag_w_.find(w.q.w.as(dt_)), fo = frag_w_.find(w.o.w.as(dt_));
+        if (fused_xattn_ && fq != frag_w_.end() && fo != frag_w_.end() && xattn_fused_supported(dt_, C, H, Lk, nb * 2 * C)) {
+            // fold (when the previous block left one), LayerNorm, q projection, attention, output projection and the residual add in ONE launch
+            if (kv_all == c.text_kv && text_gate_) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }
+            if (prof_on_) prof_begin("xattn_fused", 4.0 * M * (double)C * C + 4.0 * M * (double)Lk * C, (double)M * C * 8.0 + 2.0 * C * C * esz + (double)B * Lk * 2 * C * esz);
+            launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
+                               w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,
+                               a.larope_gamma, fs.pending ? &fs.fold : nullptr);
+            if (prof_on_) prof_end();
+            fs.pending = false;
+            return;
+        }
         const Arena::Mark m2 = ar_.mark();
         void* xn = act_alloc(M * C);
         fold_layernorm(fs, M, C, w.ln, xn, "layernorm");
@@ -892,6 +908,25 @@ int Engine::vocoder_receptive_field() const {
 // The vocoder's response to zero latent is position-independent away from data and edges.  One run on a short all-zero
 // latent yields the two pieces every padded tail is made of: the frame whose whole receptive field is zero latent ("quiet"),
 // and the last rf frames before the end of the tensor ("edge").  16-bit engines only (the packed vocoder path).
+void Engine::prepare_xattn_weights() {
+    frag_w_.clear();
+    const stn_arch& a = a_;
+    if (!is_half(dt_) || !xattn_fused_supported(dt_, a.ve_dim, a.ve_heads, 1, 8)) return;
+    for (int blk = 0; blk < a.ve_main_blocks; ++blk)
+        for (const char* kind : {".text", ".style"}) {
+            const Attn w = attn_w("ve.m" + std::to_string(blk) + kind, false);
+            for (const Linear* lin : {&w.q, &w.o}) {
+                const void* src = lin->w.as(dt_);
+                void* dst = nullptr;
+                STN_HIP(hipMalloc(&dst, (size_t)lin->N * lin->K * 2));
+                owned_.push_back(dst);
+                launch_repack_frag(s_, src, lin->N, lin->K, dst);
+                frag_w_[src] = dst;
+            }
+        }
+    sync();
+}
+
 // Fragment-ordered copies of the pointwise matrices of every ConvNeXt block the fused kernel supports (kernels_ffn.hip):
 // W1 [I][C] as phase-1 A fragments, W2 [C][I] as phase-2 A fragments in the accumulator-operand k order.
 void Engine::prepare_ffn_weights() {
@@ -1302,7 +1337,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     }
 
     GraphKey key;
-    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_;
+    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.xattn = fused_xattn_;
     key.ffn = fused_ffn_; key.gen = b.gen; key.wgen = wgen_; key.pin = pin_llen_;
     key.rows = 0;
     if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;

@@ -114,6 +114,8 @@ class Engine {
     void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr, int vrows = 0,
                      const int* valid = nullptr);
     int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
+    void prepare_xattn_weights();         // fragment-ordered copies of the estimator's cross-attention Wq / Wo (kernels_xattn.hip)
+    std::unordered_map<const void*, const void*> frag_w_;  // row-major 16-bit matrix -> its fragment-ordered copy
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
     void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
     struct FfnW { const void* wseq = nullptr; const void* wsplit[3] = {nullptr, nullptr, nullptr}; };  // wsplit: the hidden-split stage streams for S = 4, 12, 24
@@ -167,6 +169,8 @@ class Engine {
     void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
+    // cross-attention blocks of the estimator as ONE launch each (kernels_xattn.hip) instead of four
+    void set_fused_xattn(bool on) { fused_xattn_ = on; }
     // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
     // 4 = text encoder / duration predictor.  bf16 engines, widths 256 / 384 / 512 (ffn_fused_supported)
     // 8 = the estimator's blocks as K4-split (hidden dimension cut over 4 workgroups per 128-row slab, 16-bit partial sums folded
@@ -312,10 +316,10 @@ class Engine {
     // A captured graph holds raw pointers: everything it can have baked in is part of its key — the batch buffers (`gen`, bumped
     // by every reallocation), the weights (`wgen`, bumped by every load), the pinned staging the copy nodes read, the stream.
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int ffn = 0; int rows = 0, vrows = 0, trows = 0;
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false, xattn = false; int ffn = 0; int rows = 0, vrows = 0, trows = 0;
         uint64_t gen = 0, wgen = 0; const void* p0 = nullptr; const void* p1 = nullptr; const void* pin = nullptr; hipStream_t s = nullptr;
         bool operator==(const GraphKey& o) const {
-            return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged  && ffn == o.ffn &&
+            return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && xattn == o.xattn && ffn == o.ffn &&
                    rows == o.rows && vrows == o.vrows && trows == o.trows && gen == o.gen && wgen == o.wgen && p0 == o.p0 && p1 == o.p1 && pin == o.pin && s == o.s;
         }
     };
@@ -348,6 +352,7 @@ class Engine {
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int64_t ffn_split_min_rows_ = 100;   // K4-split only from this many rows on (one utterance ties with the three launches); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
+    bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip); STN_XATTN=<0|1> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }

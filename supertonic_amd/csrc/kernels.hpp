@@ -191,8 +191,19 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
                       float rope_base, float rope_gamma, bool k_rotated = false,
                       const int* q_off = nullptr /* packed query/output rows: sequence b starts at q_off[b], owns qlen[b] */,
                       const int* k_off = nullptr /* packed key/value rows: sequence b starts at k_off[b], owns klen[b] */);
+// One launch for a whole cross-attention block on rows of the residual stream (kernels_xattn.hip):
+//   x <- x + Wo . attention(Wq . LN(x) + bq, K, V) + bo, keys/values given (already projected, keys already rotated when rope_mode >= 0).
+// Supported where xattn_fused_supported() says so (16-bit modes, the vector estimator's width, contexts of <= 128 keys).
+// fold (optional): a pending K4-split update of x, folded in front of the LayerNorm (x is updated in place either way).
+bool xattn_fused_supported(int dtype, int C, int H, int Lk, int ldk);
+// Wq / Wo of launch_xattn_fused are passed in MFMA fragment order: [N][K] row-major 16-bit -> launch_repack_frag (once, at model load)
 // [N][K] row-major 16-bit -> MFMA fragment order (one contiguous KiB per operand; kernels_ffn.hip), once at model load
 void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf);
+struct FoldArgs;
+void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, const float* ln_b, float eps, const void* Wq, const float* bq,
+                        const void* kp, const void* vp, int ldk, const void* Wo, const float* bo, int B, int L, int C, int H, int Lk,
+                        const int* qlen, const int* klen, const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma,
+                        const FoldArgs* fold = nullptr);
 // in-place RoPE of `groups` key blocks per row: element (row b*L+t, column g*group_stride + h*dh + i) for t < len[b]
 // (len null: all rows).  Keys that are reused by many attention launches (the vector estimator's text keys: every
 // block of every Euler step) are rotated once here instead of at every launch.  Same arithmetic as the attention

@@ -2,7 +2,7 @@
 (oracle/stn_ref.c) on identical synthetic weights, identical inputs and injected noise.
 
 Tolerances (max |diff| and rms diff, both relative to the rms of the oracle output): every case is held to <= 2x the error
-measured for it on an MI355X (tests/golden/parity_bounds.json, recorded by tools/parity_record.py into profiles/parity_r02.json),
+measured for it on an MI355X (tests/golden/parity_bounds.json, recorded by tools/parity_record.py into profiles/parity_r03.json),
 and never looser than the mode's ceiling in gpu_util.CEILING:
   fp32 engine : per stage max <= 2e-4 ; end-to-end waveform max <= 2e-3 (5 Euler steps + vocoder compound)
   bf16 engine : per stage rms <= 2e-2, max <= 1e-1 ; end-to-end rms <= 5e-2, max <= 3e-1

@@ -1,0 +1,83 @@
+"""The fused cross-attention block of the vector estimator (kernels_xattn.hip: LayerNorm + q projection + attention + output
+projection + residual in one launch) against the four-launch form it replaces, and against the CPU oracle.
+
+The fused form is opt-in (it measured slower at batch 128 in round 1); these tests keep it correct.
+Both forms round the same intermediates to 16 bits (LN output, q, rotated q, probabilities, attention output) and accumulate
+every dot product in the same k order, so they agree far inside the 16-bit rounding of one activation."""
+import numpy as np
+import pytest
+
+from oracle.neural_ref import RefModel, randn
+from supertonic_amd import binding, host, workload
+from supertonic_amd.arch import default_arch
+from gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, min_words, max_words, seed):
+    arch = default_arch()
+    texts = workload.utterances(n, min_words=min_words, max_words=max_words, seed=seed)
+    ids, mask = host.UnicodeProcessor(host.synthetic_indexer())(texts, ["en"] * n)
+    sttl, sdp = workload.synthetic_styles(arch, list(range(n)))
+    durs = workload.forced_durations(texts) / np.float32(1.05)
+    D, L, lens = host.latent_geometry(durs, 44100, 512, 6, 24)
+    lm = (np.arange(L)[None, None, :] < np.asarray(lens)[:, None, None]).astype(np.float32)
+    return arch, ids, mask, sttl, sdp, durs, D, L, lens, lm
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 4e-3), ("f16", 5e-4)])
+@pytest.mark.parametrize("n,min_words,max_words", [(24, 2, 14), (3, 1, 3), (40, 8, 12)])
+def test_vector_est_fused_equals_unfused(dtype, tol, n, min_words, max_words):
+    arch, ids, mask, sttl, sdp, durs, D, L, lens, lm = _inputs(n, min_words, max_words, 7 + n)
+    assert ids.shape[1] <= 128  # one key chunk: the fused path is taken for the text context as well as for the style tokens
+    eng = binding.Engine(0, dtype)
+    eng.load_synthetic(arch, 7)
+    te = eng.text_enc(ids, sttl, mask)
+    xt = np.random.default_rng(3).standard_normal((n, D, L)).astype(np.float32) * lm
+    tot, cur = np.full(n, 5, np.float32), np.full(n, 2, np.float32)
+    outs = {}
+    for fused in (True, False):
+        eng.set_fused_xattn(fused)
+        outs[fused] = eng.vector_est(xt, te, sttl, mask, lm, tot, cur)
+    assert np.all(np.isfinite(outs[True]))
+    mx, rms = rel_err(outs[True], outs[False])
+    assert mx < tol and rms < tol / 4, (mx, rms)
+    assert np.all(outs[True][lm.repeat(D, axis=1) == 0] == 0)  # padding frames stay exactly zero
+    eng.set_fused_xattn(True)
+    again = eng.vector_est(xt, te, sttl, mask, lm, tot, cur)
+    assert np.array_equal(again, outs[True])
+
+
+@pytest.mark.parametrize("dtype,tol_max,tol_rms", [("bf16", 3e-1, 5e-2), ("f16", 4e-2, 8e-3)])
+def test_batch_pipeline_fused_vs_oracle_and_unfused(dtype, tol_max, tol_rms):
+    """Whole resident-batch synthesis (packed rows, graph replay) with the fused blocks: against the oracle at the usual bounds,
+    against the four-launch form tightly, replays bit-stable."""
+    arch, ids, mask, sttl, sdp, durs, D, L, lens, lm = _inputs(6, 3, 9, 5)
+    ref = RefModel(arch, 7)
+    nz = {}
+
+    def nf(B, Dn, Ln):
+        nz["x"] = randn(11, B, Dn, Ln)
+        return nz["x"]
+
+    fd = durs * np.float32(1.05)
+    ref_wav, _ = ref.synthesize(ids, mask, sttl, sdp, 3, 1.05, nf, duration_override=fd)
+    eng = binding.Engine(0, dtype)
+    eng.load_synthetic(arch, 7)
+    wavs = {}
+    for fused in (True, False):
+        eng.set_fused_xattn(fused)
+        wavs[fused], _ = eng.synthesize(ids, mask, sttl, sdp, 3, 1.05, noise=nz["x"], duration_override=fd)
+    mx, rms = rel_err(wavs[True], ref_wav)
+    assert mx < tol_max and rms < tol_rms, (mx, rms)
+    mx, rms = rel_err(wavs[True], wavs[False])
+    assert mx < tol_max / 10 and rms < tol_rms / 10, (mx, rms)
+    eng.set_fused_xattn(True)
+    eng.batch_upload(ids, mask, sttl, sdp, duration_override=fd)
+    first = None
+    for _ in range(4):  # the second run captures the hipGraph, the following ones replay it
+        eng.batch_run(3, 1.05, 1234)
+        w, _ = eng.batch_fetch()
+        first = w.copy() if first is None else first
+        assert np.array_equal(w, first)
