@@ -70,7 +70,14 @@ const char* stn_last_error(const stn_handle* h);
  *    "transpose": false}, ...}}   ("transpose" may be omitted: it is inferred from the stored dims, which are checked either way).
  * STN_ERR_IO: a file is missing/unreadable/malformed ("Failed to open ..." as cpp/helper.cpp:805) or does not bind;
  * STN_ERR_INVALID: the derived descriptor is outside what the kernels support (message names the field).
- * After a successful manifest-less load stn_last_error holds notes on what the graphs did not state (e.g. head counts). */
+ * After a successful manifest-less load stn_last_error holds notes (e.g. that the graphs spell GELU with Tanh).  A head count the graphs do
+ * not carry (no [batch, length, heads, head_dim] Reshape constant) is an ERROR, not a default: state it in a stn_weight_map.json that has only
+ * {"arch": {"te_heads": n, "dp_heads": n, "ve_heads": n}} (no "tensors" table: the graphs are still walked).
+ * Accepted spellings of the layout: LayerNormalization as one node or decomposed (ReduceMean / Sub / Pow / ReduceMean / Add / Sqrt / Div / Mul /
+ * Add), q / k / v projections separate or fused (3C or 2C rows + Split), pointwise convolutions as Conv k=1, MatMul(+Add) with Transposes around it
+ * or Gemm, GELU as a node or written with Erf / Tanh.  VERIFIED ON GRAPHS THE TESTS EMIT (tests/onnx_graphs.py), not on the published files, which
+ * are not available offline: for real assets the explicit stn_weight_map.json below is the documented path, and the walk says where a graph departs
+ * from the layout. */
 int stn_load_dir(stn_handle* h, const char* onnx_dir);
 /* '\n'-separated names of every canonical tensor the descriptor implies (what a manifest must map); returns bytes needed */
 int stn_tensor_names(stn_handle* h, const stn_arch* arch, char* out, size_t cap);

@@ -228,9 +228,16 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
                                                            const float* __restrict__ w_t, const float* __restrict__ bias,
                                                            int dil, int wps /*waves per sequence*/, const float* __restrict__ g,
                                                            const float* __restrict__ bt, float eps, OutT* __restrict__ y,
-                                                           const int* __restrict__ seqlen, const int* __restrict__ row_off) {
+                                                           const int* __restrict__ seqlen, const int* __restrict__ row_off, int xcd_runs) {
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Workgroups are dealt to the 8 XCDs round-robin, and each XCD has its own L2: with the plain order the two workgroups that share a halo
+    // (neighbours in time) sit on different XCDs and both fetch it over the fabric.  Give each XCD one contiguous run of tiles instead.
+    int bid = blockIdx.x;
+    if (xcd_runs) {
+        const int nb = gridDim.x, q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = xcd * q + (xcd < rr ? xcd : rr) + idx;
+    }
+    const int64_t wid = (int64_t)bid * 4 + (threadIdx.x >> 6);
     if (wid >= (int64_t)nseq * wps) return;  // wave-uniform
     const int b = (int)(wid / wps), rem = (int)(wid % wps);
     const int t0 = (rem / dil) * (R * dil) + (rem % dil);
@@ -331,8 +338,9 @@ static void launch_dwconv_ln_v3_kr(hipStream_t s, const float* x, int nseq, int 
                                    const int* row_off = nullptr) {
     const int wps = ((L + R * dil - 1) / (R * dil)) * dil;
     const int64_t nw = (int64_t)nseq * wps;
+    static const int xcd_runs = [] { const char* e = getenv("STN_DWCONV_XCD"); return e ? atoi(e) : 1; }();  // A/B switch
     STN_KLAUNCH((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
-                       dil, wps, g, b, eps, y, seqlen, row_off);
+                       dil, wps, g, b, eps, y, seqlen, row_off, xcd_runs);
 }
 
 template <typename OutT>

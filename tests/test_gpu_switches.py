@@ -1,0 +1,99 @@
+"""Every diagnostic switch of the engine (environment variables read at stn_create / at a kernel's first launch; DESIGN.md "Switches") is a
+configuration somebody will run: each one is driven here through a whole synthesis of the default (full-width) descriptor in a fresh process and
+held against the default configuration — bit-equal where the switch only moves work between streams, within the dtype's recorded bound where it
+picks another kernel form (stn.h, "WHAT IS AND IS NOT BIT-IDENTICAL").  A malformed value must not take the process down either."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from supertonic_amd import binding
+from supertonic_amd.arch import default_arch
+from gpu_util import make_inputs
+a = default_arch()
+out = {}
+for dtype in ("bf16", "f32"):
+    eng = binding.Engine(0, dtype)
+    eng.load_synthetic(a, 11)
+    B, Lt = 24, 40
+    lens = np.array([Lt] + [5 + (7 * i) % (Lt - 5) for i in range(B - 1)])
+    ids, mask, sttl, sdp = make_inputs(a, B, Lt, lens, seed=4)
+    durs = np.linspace(0.4, 2.6, B).astype(np.float32)
+    w, d = eng.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=5)
+    w2, d2 = eng.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=5)   # the replayed graph
+    assert np.array_equal(w, w2) and np.array_equal(d, d2)
+    # the predictor's own lengths too (no override)
+    _, dp = eng.synthesize(ids, mask, sttl, sdp, 1, 1.05, noise_seed=5)
+    np.save(sys.argv[2] + "_" + dtype + ".npy", w)
+    out[dtype] = {"sha": hashlib.sha256(w.tobytes()).hexdigest(), "dur": [float(x) for x in dp], "rows": int(eng.ve_rows)}
+print("RESULT " + json.dumps(out))
+"""
+
+# switch -> (value, "equal" | "bound")
+SWITCHES = [
+    ("STN_DP_STREAM", "0", "equal"),       # duration predictor / text encoder on the main stream instead of beside it
+    ("STN_PACKED", "0", "bound"),          # padded rows: other launch shapes, so other kernel forms (K4-split threshold)
+    ("STN_NT", "0", "equal"),              # streaming-store hints off
+    ("STN_FFN", "0", "bound"),             # every pointwise pair as two GEMM launches
+    ("STN_FFN", "1", "bound"),             # K4 without the hidden split
+    ("STN_FFN_SPLIT_S", "4", "bound"),     # the 4-way split at every size
+    ("STN_FFN_SPLIT_MIN_ROWS", "100000", "bound"),
+    ("STN_FFN_MIN_ROWS", "1", "bound"),    # vocoder K4 at every size
+    ("STN_GEMM_TR", "0", "bound"),
+    ("STN_XATTN", "1", "bound"),           # the one-launch cross-attention block (opt-in)
+    ("STN_FFN", "banana", "bound"),        # malformed: falls back to a documented value, never crashes
+    ("STN_FFN_SPLIT_S", "5", "bound"),     # not a supported split: ignored
+]
+
+
+def _run(tmp, tag, env_extra):
+    env = dict(os.environ)
+    for k in [s[0] for s in SWITCHES]:
+        env.pop(k, None)
+    env.update(env_extra)
+    prefix = os.path.join(tmp, tag)
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, prefix], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (tag, r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[7:])
+    for dt in res:
+        res[dt]["wav"] = np.load(prefix + "_" + dt + ".npy")
+    return res
+
+
+def test_every_environment_switch_against_the_default(tmp_path):
+    tmp = str(tmp_path)
+    base = _run(tmp, "default", {})
+    again = _run(tmp, "default2", {})
+    for dt in base:
+        assert base[dt]["sha"] == again[dt]["sha"], dt   # process-to-process determinism of the default
+    bounds = {"bf16": 6e-2, "f32": 5e-5}
+    for i, (name, val, kind) in enumerate(SWITCHES):
+        got = _run(tmp, "s%d" % i, {name: val})
+        for dt in base:
+            # the predictor runs fp32 in every engine: its durations are bit-equal under the switches that only move work, and equal to fp32
+            # rounding under those that change a launch's row count or tile (padded text rows leave the M <= 512 split-K regime of the fp32 GEMM:
+            # another summation order, stn.h "WHAT IS AND IS NOT BIT-IDENTICAL")
+            if kind == "equal":
+                assert got[dt]["dur"] == base[dt]["dur"], (name, val, dt)
+            else:
+                np.testing.assert_allclose(got[dt]["dur"], base[dt]["dur"], rtol=2e-5, err_msg=str((name, val, dt)))
+            w0, w1 = base[dt]["wav"], got[dt]["wav"]
+            assert w0.shape == w1.shape
+            if kind == "equal":
+                assert got[dt]["sha"] == base[dt]["sha"], (name, val, dt)
+            else:
+                scale = float(np.max(np.abs(w0))) + 1e-12
+                mx = float(np.max(np.abs(w0.astype(np.float64) - w1))) / scale
+                assert mx < bounds[dt], (name, val, dt, mx)
