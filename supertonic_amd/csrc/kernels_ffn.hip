@@ -111,6 +111,82 @@ namespace v_nord {
 #undef STN_V_NOGELU
 #undef STN_V_EARLYRD
 }
+namespace v_nobar {
+#define STN_V_NODMA 0
+#define STN_V_NOGELU 0
+#define STN_V_EARLYRD 0
+#define STN_V_NOBAR 1
+#ifndef STN_V_ACCA
+#define STN_V_ACCA 0
+#endif
+#include "kernels_ffn_body.inc"
+#undef STN_V_NODMA
+#undef STN_V_NOGELU
+#undef STN_V_EARLYRD
+#undef STN_V_NOBAR
+#undef STN_HANDOVER
+}
+namespace v_nohand {
+#define STN_V_NODMA 0
+#define STN_V_NOGELU 0
+#define STN_V_EARLYRD 0
+#define STN_V_NOBAR 2
+#ifndef STN_V_ACCA
+#define STN_V_ACCA 0
+#endif
+#include "kernels_ffn_body.inc"
+#undef STN_V_NODMA
+#undef STN_V_NOGELU
+#undef STN_V_EARLYRD
+#undef STN_V_NOBAR
+#undef STN_HANDOVER
+}
+namespace v_mfmaonly {
+#define STN_V_NODMA 1
+#define STN_V_NOGELU 1
+#define STN_V_EARLYRD 2
+#define STN_V_NOBAR 2
+#ifndef STN_V_ACCA
+#define STN_V_ACCA 0
+#endif
+#include "kernels_ffn_body.inc"
+#undef STN_V_NODMA
+#undef STN_V_NOGELU
+#undef STN_V_EARLYRD
+#undef STN_V_NOBAR
+#undef STN_HANDOVER
+}
+namespace v_stamp {
+#define STN_V_NODMA 0
+#define STN_V_NOGELU 0
+#define STN_V_EARLYRD 0
+#define STN_V_STAGESTAMP 1
+#ifndef STN_V_ACCA
+#define STN_V_ACCA 0
+#endif
+#include "kernels_ffn_body.inc"
+#undef STN_V_NODMA
+#undef STN_V_NOGELU
+#undef STN_V_EARLYRD
+#undef STN_V_STAGESTAMP
+}
+namespace v_stamp_mfma {
+#define STN_V_NODMA 1
+#define STN_V_NOGELU 1
+#define STN_V_EARLYRD 2
+#define STN_V_NOBAR 2
+#define STN_V_STAGESTAMP 1
+#ifndef STN_V_ACCA
+#define STN_V_ACCA 0
+#endif
+#include "kernels_ffn_body.inc"
+#undef STN_V_NODMA
+#undef STN_V_NOGELU
+#undef STN_V_EARLYRD
+#undef STN_V_NOBAR
+#undef STN_V_STAGESTAMP
+#undef STN_HANDOVER
+}
 namespace v_bare {
 #define STN_V_NODMA 1
 #define STN_V_NOGELU 1
@@ -239,6 +315,11 @@ static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
     if (var == 3) { go(&v_earlyrd::ffn_fused_kernel<C>); return; }
     if (var == 4) { go(&v_bare::ffn_fused_kernel<C>); return; }
     if (var == 5) { go(&v_nord::ffn_fused_kernel<C>); return; }
+    if (var == 6) { go(&v_nobar::ffn_fused_kernel<C>); return; }
+    if (var == 7) { go(&v_nohand::ffn_fused_kernel<C>); return; }
+    if (var == 8) { go(&v_mfmaonly::ffn_fused_kernel<C>); return; }
+    if (var == 9) { go(&v_stamp::ffn_fused_kernel<C>); return; }
+    if (var == 10) { go(&v_stamp_mfma::ffn_fused_kernel<C>); return; }
 #endif
     if (dtype == F16) {
         static PerDeviceOnce attr16;
