@@ -263,7 +263,9 @@ void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I
 // LDS of one workgroup: the 4-stage ring, b2 / gamma / b1 behind it; the split form's epilogue re-uses it as four wave-private
 // row images of 32 x (2C + 16) bytes
 static size_t ffn_lds_bytes(int C, int I) {
-    const size_t ring = (size_t)4 * C * 64 + (size_t)(I + 2 * C) * 4, img = (size_t)4 * 32 * (C * 2 + 16);
+    size_t ring = (size_t)4 * C * 64 + (size_t)(I + 2 * C) * 4;
+    if (C == 384) ring = ((ring + 1023) & ~(size_t)1023) + (size_t)C * 64;  // a fifth buffer: wave 0's rows of the slab in the prologue (kernels_ffn_body.inc)
+    const size_t img = (size_t)4 * 32 * (C * 2 + 16);
     return ring > img ? ring : img;
 }
 
