@@ -8,6 +8,7 @@
 // never touch HBM.  fp32 math in both precisions; LDS rows are dh+1 words (odd stride: conflict-free).
 // Thread (qi = tid / 8, g = tid % 8): scores for keys g + 8*jj, output columns g + 8*i of query row qi.
 #include "kernels.hpp"
+#include "kernels_dev.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -257,7 +258,7 @@ extern "C" void stn_dbg_attn_ts(unsigned long long* out) { (void)hipDeviceSynchr
 #define ATTN_STAMP(i) do { } while (0)
 #endif
 template <int DH, bool F16>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const uint16_t* __restrict__ q, int ldq,
                                                         const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                         int ldk, uint16_t* __restrict__ o, int ldo, int Lq, int Lk,
                                                         int kc /* keys per LDS chunk: multiple of 32, <= 128 */,
@@ -290,34 +291,44 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     }
     constexpr int CH = HD2 / 8;  // 16-byte chunks per half row
     // ---- staging of Q (pass 0: 128 rows from q0) or of a chunk of K (pass 1: kc rows from key c0): RoPE in fp32, stored
-    // bf16; 8 pairs per thread-iteration, 16-byte loads and LDS stores ----------------------------------------------------
-    auto stage_rows = [&](int pass, int c0) {
-        const uint16_t* src = pass == 0 ? q + h * DH : k + h * DH;
+    // 16-bit; 8 pairs per item, 16-byte loads and LDS stores.  A thread owns items tid, tid + 256, ...: ALL their loads are issued
+    // first (unconditional buffer loads: an item outside the tile or the sequence reads zeros through the range check), the
+    // arithmetic and the LDS stores follow — one memory round trip per staging step instead of one per item.  With one key chunk
+    // (the estimator's cross-attention) the loads of Q, K and V are all in flight before the first store.
+    constexpr int RN = (128 * CH + 255) / 256;        // items per thread of a 128-row tile
+    constexpr int VN = (128 * (DH / 8) + 255) / 256;  // items per thread of a 128-key chunk of V
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(q, 0x7FFFFFFFu), rs_k = make_rsrc(k, 0x7FFFFFFFu), rs_v = make_rsrc(v, 0x7FFFFFFFu);
+    auto issue_rows = [&](int pass, int c0, u32x4_t (&w0)[RN], u32x4_t (&w1)[RN]) __attribute__((always_inline)) {
         const int ld = pass == 0 ? ldq : ldk;
         const int64_t seq_base = pass == 0 ? qrow0 : krow0;
         const int pos0 = pass == 0 ? q0 : c0, rows = pass == 0 ? 128 : kc, limit = pass == 0 ? qrows : nk;
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+            const int idx = tid + 256 * i, r = idx / CH, c = idx - r * CH, pos = pos0 + r;
+            const unsigned off = (idx < rows * CH && pos < limit) ? (unsigned)(((seq_base + pos) * ld + h * DH + c * 8) * 2) : OOB;
+            w0[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pass == 0 ? rs_q : rs_k, off, 0, 0));
+            w1[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pass == 0 ? rs_q : rs_k, off, HD2 * 2, 0));
+        }
+    };
+    auto commit_rows = [&](int pass, int c0, const u32x4_t (&w0)[RN], const u32x4_t (&w1)[RN]) __attribute__((always_inline)) {
+        const int pos0 = pass == 0 ? q0 : c0, rows = pass == 0 ? 128 : kc;
         const int seq_len = pass == 0 ? nq : nk;
         const float mul = pass == 0 ? qmul : 1.f;
         const bool rot = rope_mode >= 0 && !(pass == 1 && k_rot);
         const float pscale = rope_mode == 1 ? gamma / (float)(seq_len > 0 ? seq_len : 1) : 1.f;
         unsigned char* dst = pass == 0 ? Qs : Ks;
-        for (int idx = tid; idx < rows * CH; idx += 256) {
-            const int r = idx / CH, c = idx - r * CH;
-            const int pos = pos0 + r;
-            u32x4_t w0 = {0u, 0u, 0u, 0u}, w1 = w0;
-            if (pos < limit) {
-                const uint16_t* p = src + (seq_base + pos) * ld + c * 8;
-                w0 = *reinterpret_cast<const u32x4_t*>(p);
-                w1 = *reinterpret_cast<const u32x4_t*>(p + HD2);
-            }
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+            const int idx = tid + 256 * i, r = idx / CH, c = idx - r * CH, pos = pos0 + r;
+            if (idx >= rows * CH) continue;
             u32x4_t o0, o1;
             if (rot || mul != 1.f) {
                 const float pp = (float)pos * pscale;
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
                     float a0[2], a1[2];
-                    unpack_h2<F16>(w0[e2], a0[0], a0[1]);
-                    unpack_h2<F16>(w1[e2], a1[0], a1[1]);
+                    unpack_h2<F16>(w0[i][e2], a0[0], a0[1]);
+                    unpack_h2<F16>(w1[i][e2], a1[0], a1[1]);
                     float y0[2], y1[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -334,26 +345,45 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
                     o1[e2] = pack_h2<F16>(y1[0], y1[1]);
                 }
             } else {
-                o0 = w0; o1 = w1;
+                o0 = w0[i]; o1 = w1[i];
             }
             *reinterpret_cast<u32x4_t*>(dst + r * QS + c * 16) = o0;
             *reinterpret_cast<u32x4_t*>(dst + r * QS + HD2 * 2 + c * 16) = o1;
         }
     };
     // ---- a chunk of V, transposed ---------------------------------------------------------------------------------------
-    auto stage_v = [&](int c0) {
-        for (int idx = tid; idx < kc * (DH / 8); idx += 256) {
-            const int kl = idx / (DH / 8), c = idx - kl * (DH / 8);
-            const int key = c0 + kl;
-            u32x4_t w = {0u, 0u, 0u, 0u};
-            if (key < nk) w = *reinterpret_cast<const u32x4_t*>(v + (krow0 + key) * ldk + h * DH + c * 8);
+    auto issue_v = [&](int c0, u32x4_t (&w)[VN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            const int idx = tid + 256 * i, kl = idx / (DH / 8), c = idx - kl * (DH / 8), key = c0 + kl;
+            const unsigned off = (idx < kc * (DH / 8) && key < nk) ? (unsigned)(((krow0 + key) * ldk + h * DH + c * 8) * 2) : OOB;
+            w[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, 0, 0));
+        }
+    };
+    auto commit_v = [&](const u32x4_t (&w)[VN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            const int idx = tid + 256 * i, kl = idx / (DH / 8), c = idx - kl * (DH / 8);
+            if (idx >= kc * (DH / 8)) continue;
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                const unsigned word = w[e2];
+                const unsigned word = w[i][e2];
                 *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2) * VS + kl * 2) = (uint16_t)(word & 0xFFFFu);
                 *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * e2 + 1) * VS + kl * 2) = (uint16_t)(word >> 16);
             }
         }
+    };
+    auto stage_rows = [&](int pass, int c0) __attribute__((always_inline)) {
+        u32x4_t w0[RN], w1[RN];
+        issue_rows(pass, c0, w0, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        commit_rows(pass, c0, w0, w1);
+    };
+    auto stage_v = [&](int c0) __attribute__((always_inline)) {
+        u32x4_t w[VN];
+        issue_v(c0, w);
+        __builtin_amdgcn_sched_barrier(0);
+        commit_v(w);
     };
 
     const int qbase = wave * 32;
@@ -431,12 +461,17 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
         }
     };
 
-    stage_rows(0, 0);
-    ATTN_STAMP(1);
     if (nch == 1) {  // the whole context fits one chunk: K is staged once and serves both passes
-        stage_rows(1, 0);
+        u32x4_t qa[RN], qb[RN], ka[RN], kb[RN], va[VN];
+        issue_rows(0, 0, qa, qb);
+        issue_rows(1, 0, ka, kb);
+        issue_v(0, va);
+        __builtin_amdgcn_sched_barrier(0);
+        commit_rows(0, 0, qa, qb);
+        ATTN_STAMP(1);
+        commit_rows(1, 0, ka, kb);
         ATTN_STAMP(2);
-        stage_v(0);
+        commit_v(va);
         __syncthreads();
         ATTN_STAMP(3);
         if (active) {
@@ -447,6 +482,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
             pass_pv(0);
         }
     } else {  // long contexts (up to ~320 text tokens): K streams through the chunk buffer twice, V once
+        stage_rows(0, 0);
         for (int c = 0; c < nch; ++c) {
             if (c) __syncthreads();  // every wave is done with the previous chunk
             stage_rows(1, c * kc);
@@ -514,8 +550,10 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
     if (B == 0 || Lq == 0) return;
     if ((q_off && !qlen) || (k_off && !klen)) { throw std::invalid_argument("packed attention needs the lengths of the packed side"); }
     if (dh > ADH_MAX || dh % 8 || dh < 8) { char m_[256]; snprintf(m_, sizeof m_, "attention head dim %d unsupported (multiple of 8, <= %d)", dh, ADH_MAX); throw std::invalid_argument(m_); }
+    // (the MFMA kernel addresses q, k and v through 32-bit buffer offsets: operands of 2 GiB and more take the scalar kernel)
     if (is_half(dtype) && (dh == 32 || dh == 64 || dh == 96) && ldk % 8 == 0 && ldq % 8 == 0 && !(reinterpret_cast<uintptr_t>(v) & 15) &&
-        !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15)) {
+        !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15) && (int64_t)B * Lq * ldq * 2 < 0x7FFFFFFFll &&
+        (int64_t)B * Lk * ldk * 2 < 0x7FFFFFFFll) {
         // keys go through LDS in chunks of at most 128 (one chunk covers the 50 style tokens and ~100-token texts; longer texts
         // take several), so the MFMA kernel serves every context length at 2 workgroups per CU
         const int lk_pad = (Lk + 31) & ~31;
