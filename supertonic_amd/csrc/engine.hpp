@@ -350,7 +350,7 @@ class Engine {
     bool copied_valid_ = false;
     int64_t ffn_gate_rows_ = 0;     // row count the K4 decision is taken on when it is not the launch's own (trimmed dense vocoder)
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
-    int64_t ffn_split_min_rows_ = 100;   // K4-split only from this many rows on (one utterance ties with the three launches); STN_FFN_SPLIT_MIN_ROWS overrides
+    int64_t ffn_split_min_rows_ = 1;     // K4-split from this many rows on (with the slab staged through LDS one utterance gains too: 20.0 vs 21.4 us per block); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
     bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip); STN_XATTN=<0|1> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
