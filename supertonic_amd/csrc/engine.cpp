@@ -1994,7 +1994,7 @@ void Engine::op_block_bench(int B, int L, int C, int I, int k, int dil, int mode
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     if (mode == 2) {  // phase stamps of one fold_dwconv_ln launch
-        const int nwg = B * ((L + 31) / 32);
+        const int nwg = B * ((L + 7) / 8);  // (runs of 8 frames when there are few sequences, of 32 otherwise: sized for the shorter)
         unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
         STN_HIP(hipMemsetAsync(ts, 0, sizeof(unsigned long long) * 4 * (size_t)nwg, s_));
         fo.ts = ts;

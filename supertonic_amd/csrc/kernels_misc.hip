@@ -526,7 +526,9 @@ void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, co
 // the chain is ONE global round trip long — the conv / LayerNorm parameters ride to LDS beside the phase-1 loads (no global load
 // behind the barrier), nothing is stored to global memory before the barrier (a store in flight would be waited for there), and
 // the x_out stores are the last thing a thread issues.
-static constexpr int FOLD_TCH = 32, FOLD_NT = 1024;  // FOLD_TCH == 2 * wavefronts per workgroup
+// Few sequences (a single utterance: two workgroups) are cut into runs of 8 frames instead: more workgroups, one pass of phase-1 loads each
+// instead of two to four dependent ones; a frame's arithmetic does not depend on the run it falls in, so the result is the same bit for bit.
+static constexpr int FOLD_TCH = 32, FOLD_TCH_FEW = 8, FOLD_NT = 1024;  // FOLD_TCH == 2 * wavefronts per workgroup (the longest run)
 template <typename OutT, bool F16, int K, bool RV, int FOLD_NSLOT /* float4 slots per lane of a half wavefront: ceil(C / 128) */, int S>
 __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __restrict__ xin, float* __restrict__ xout, int cps, int C,
                                                                  const uint16_t* __restrict__ part, int64_t pstride,
@@ -535,14 +537,14 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
                                                                  const float* __restrict__ bias, int dil, const float* __restrict__ g,
                                                                  const float* __restrict__ bt, float eps, float inv_c, OutT* __restrict__ y,
                                                                  const int* __restrict__ seqlen, const int* __restrict__ row_off,
-                                                                 unsigned long long* __restrict__ ts) {
+                                                                 unsigned long long* __restrict__ ts, int tch /* frames per run: FOLD_TCH or FOLD_TCH_FEW */) {
     extern __shared__ __attribute__((aligned(16))) float fold_sm[];
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if (ts) st0 = __builtin_readcyclecounter();
     const int b = (int)blockIdx.x / cps, c = (int)blockIdx.x % cps;
     const int Lv = seqlen[b];
     const int64_t row0 = (int64_t)row_off[b];
-    const int nch = (Lv + FOLD_TCH - 1) / FOLD_TCH;
+    const int nch = (Lv + tch - 1) / tch;
     if (c >= nch) return;
     const int per = (Lv + nch - 1) / nch;
     const int t0 = c * per, t1 = min(t0 + per, Lv);
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     const int w0 = max(t0 - HALF * dil, 0), w1 = min(t1 + HALF * dil, Lv), nw = w1 - w0;
     const int tid = threadIdx.x, C8 = C >> 3, C4 = C >> 2;
     // the parameters of phase 2 as one LDS block behind the image: [K taps][C] | conv bias | LayerNorm g | LayerNorm b
-    float* const zrow = fold_sm + (size_t)(FOLD_TCH + (K - 1) * dil) * C;  // a row of zeros: what a tap outside the sequence reads
+    float* const zrow = fold_sm + (size_t)(tch + (K - 1) * dil) * C;  // a row of zeros: what a tap outside the sequence reads
     float* const wsm = zrow + C;
     constexpr int NPV = (K + 3 + 7) / 8;  // float4 per thread: (K + 3) * C4 <= NPV * FOLD_NT for C <= 512, K <= 7 ... checked by the launcher
     float4 pv[NPV];
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     }
 }
 
-static size_t fold_dwconv_lds(int C, int k, int dil) { return ((size_t)(FOLD_TCH + (k - 1) * dil) + 1 + (size_t)(k + 3)) * C * 4; }  // image + zero row + parameter block
+static size_t fold_dwconv_lds(int C, int k, int dil, int tch = FOLD_TCH) { return ((size_t)(tch + (k - 1) * dil) + 1 + (size_t)(k + 3)) * C * 4; }  // image + zero row + parameter block
 bool fold_dwconv_ln_supported(int C, int k, int dil) {
     return C % 8 == 0 && C <= 512 && (k == 5 || k == 7) && dil >= 1 && fold_dwconv_lds(C, k, dil) <= 160 * 1024;
 }
@@ -701,9 +703,11 @@ static void launch_fold_dwconv_ln_t3(hipStream_t s, const float* x_in, float* x_
     if (attr_once.need())
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024), "hipFuncSetAttribute(fold_dwconv_ln)");
-    const int cps = (L + FOLD_TCH - 1) / FOLD_TCH;
-    STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil), s, x_in, x_out, cps, C,
-                static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, 1.0f / (float)C, y, seqlen, row_off, f.ts);
+    static const int force = [] { const char* e = getenv("STN_FOLD_TCH"); return e ? atoi(e) : 0; }();  // A/B switch: 8 or 32
+    const int tch = force == FOLD_TCH || force == FOLD_TCH_FEW ? force : (int64_t)B * ((L + FOLD_TCH - 1) / FOLD_TCH) < 64 ? FOLD_TCH_FEW : FOLD_TCH;
+    const int cps = (L + tch - 1) / tch;
+    STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil, tch), s, x_in, x_out, cps, C,
+                static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, 1.0f / (float)C, y, seqlen, row_off, f.ts, tch);
 }
 template <typename OutT, bool F16, int K, bool RV, int NSLOT>
 static void launch_fold_dwconv_ln_t2(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
@@ -724,7 +728,7 @@ void launch_fold_dwconv_ln(hipStream_t s, int act_dtype, const float* x_in, floa
                            const int* row_off) {
     if (B == 0 || L == 0) return;
     if (!is_half(act_dtype) || !seqlen || !row_off || x_in == x_out || !fold_dwconv_ln_supported(C, k, dil) ||
-        (int64_t)B * ((L + FOLD_TCH - 1) / FOLD_TCH) > 0x7FFFFFFFll)
+        (int64_t)B * ((L + FOLD_TCH_FEW - 1) / FOLD_TCH_FEW) > 0x7FFFFFFFll)
         throw std::invalid_argument("launch_fold_dwconv_ln: packed 16-bit rows, separate output, k in {5,7}, C % 8 == 0, C <= 512 needed");
     check_fold_args(f, 0, C, "launch_fold_dwconv_ln");
 #define STN_FOLD_DW(OUT, F16_, K_) do { if (f.rowvec) launch_fold_dwconv_ln_t<OUT, F16_, K_, true>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, ln_g, ln_b, eps, static_cast<OUT*>(y), seqlen, row_off); \

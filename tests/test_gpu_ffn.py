@@ -270,6 +270,30 @@ def test_fold_dwconv_ln_vs_numpy(eng, k, dil, C, S):
         assert rms < 4e-3 and mx < 4e-2, (mx, rms)  # one bf16 rounding of the normalised output (2^-9 of values up to ~5 sigma)
 
 
+def test_fold_dwconv_ln_run_length_does_not_change_a_bit(eng):
+    """Few sequences are cut into runs of 8 frames, many into runs of 32 (kernels_misc.hip, FOLD_TCH_FEW): a frame's arithmetic does not depend
+    on the run it falls in, so three sequences alone and the same three among forty give the same bits."""
+    rng = np.random.default_rng(77)
+    C, S, k = 384, 12, 5
+    lens_few = np.array([49, 70, 9], np.int32)
+    lens_many = np.concatenate([lens_few, rng.integers(20, 90, 37).astype(np.int32)])
+    assert len(lens_few) * ((lens_few.max() + 31) // 32) < 64 <= len(lens_many) * ((lens_many.max() + 31) // 32)
+    M = int(lens_many.sum()); m = int(lens_few.sum())
+    x = rng.standard_normal((M, C)).astype(np.float32)
+    part = bf16_round((0.5 * rng.standard_normal((S, M, C))).astype(np.float32))
+    b2 = (0.3 * rng.standard_normal(C)).astype(np.float32)
+    gamma = (0.5 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    rowvec = rng.standard_normal((len(lens_many), C)).astype(np.float32)
+    w = (rng.standard_normal((C, k)) / np.sqrt(k)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    for dil in (1, 8):
+        xo1, y1 = eng.op_fold_dwconv_ln(lens_few, x[:m].copy(), np.ascontiguousarray(part[:, :m]), b2, gamma, rowvec[:3].copy(), w, bias, g, b, k, dil)
+        xo2, y2 = eng.op_fold_dwconv_ln(lens_many, x, part, b2, gamma, rowvec, w, bias, g, b, k, dil)
+        assert np.array_equal(xo1, xo2[:m]) and np.array_equal(y1, y2[:m]), dil
+
+
 # ---- the fused forms INSIDE the engine (ADVICE round 2): stage-ordered weight packing, FfnArgs wiring, fold state, every stage mask ----
 
 def _mid_arch():
