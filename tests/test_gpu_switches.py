@@ -52,6 +52,9 @@ SWITCHES = [
     ("STN_FFN_MIN_ROWS", "1", "bound"),    # vocoder K4 at every size
     ("STN_GEMM_TR", "0", "bound"),
     ("STN_XATTN", "1", "bound"),           # the one-launch cross-attention block (opt-in)
+    ("STN_FOLD_TCH", "8", "equal"),        # the fold kernel's run length: the same bits either way
+    ("STN_FOLD_TCH", "32", "equal"),
+    ("STN_DWCONV_XCD", "0", "equal"),      # tile order of the comb kernel: placement only
     ("STN_FFN", "banana", "bound"),        # malformed: falls back to a documented value, never crashes
     ("STN_FFN_SPLIT_S", "5", "bound"),     # not a supported split: ignored
 ]
