@@ -127,8 +127,9 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
 /* Cross-attention blocks of the vector estimator: 0 = four launches (LayerNorm, q projection, attention, output projection +
- * residual), 1 = one fused launch per block (16-bit modes, contexts of <= 128 keys; longer contexts take the four launches).  Same
- * result up to the rounding of the 16-bit intermediates (tests/test_gpu_xattn.py). */
+ * residual), 1 = one fused launch per block, 2 = two launches cut behind the q projection (the fused kernel's phases; both 16-bit
+ * modes only, contexts of <= 128 keys; longer contexts take the four launches).  Same result up to the rounding of the 16-bit
+ * intermediates; 1 and 2 give the same bits (tests/test_gpu_xattn.py).  Other values: 0. */
 int stn_set_fused_xattn(stn_handle* h, int on);
 /* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
  * activation never leaves the registers (bf16 and f16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip

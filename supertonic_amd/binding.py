@@ -285,8 +285,8 @@ class Engine:
         self._ck(self._lib.stn_set_fused_ffn(self._h, int(mask)))
 
     def set_fused_xattn(self, on=True):
-        """Cross-attention blocks of the vector estimator as one fused launch each or as four launches."""
-        self._ck(self._lib.stn_set_fused_xattn(self._h, int(bool(on))))
+        """Cross-attention blocks of the vector estimator: 0 / False four launches, 1 / True one fused launch, 2 two launches."""
+        self._ck(self._lib.stn_set_fused_xattn(self._h, int(on)))
 
     @property
     def vo_rows(self):

@@ -267,7 +267,7 @@ int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_m
 int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows() : 0; }
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
-int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_xattn(on != 0); }) }
+int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_xattn(on); }) }
 int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 15, "stage mask must be in 0..15"); h->eng->set_fused_ffn(mask); }) }
 int stn_set_fused_ffn_min_rows(stn_handle* h, int64_t k4_rows, int64_t split_rows) { STN_TRY(h, { h->eng->set_fused_ffn_min_rows(k4_rows, split_rows); }) }
 int stn_set_vocoder_mode(stn_handle* h, int length_aware) { STN_TRY(h, { h->eng->set_vocoder_mode(length_aware != 0); }) }

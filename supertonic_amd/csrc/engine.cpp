@@ -116,7 +116,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
-    if (const char* p = getenv("STN_XATTN")) fused_xattn_ = atoi(p) != 0;  // A/B switch: one launch per cross-attention block
+    if (const char* p = getenv("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks in one (1) or two (2) launches
     if (const char* p = getenv("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
@@ -836,6 +836,23 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         if (fused_xattn_ && fq != frag_w_.end() && fo != frag_w_.end() && xattn_fused_supported(dt_, C, H, Lk, nb * 2 * C)) {
             // fold (when the previous block left one), LayerNorm, q projection, attention, output projection and the residual add in ONE launch
             if (kv_all == c.text_kv && text_gate_) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }
+            if (fused_xattn_ == 2) {  // two launches, the q rows through a buffer
+                const Arena::Mark m2 = ar_.mark();
+                void* qb = act_alloc(M * C);
+                if (prof_on_) prof_begin("xattn_q", 2.0 * M * (double)C * C, (double)M * C * (8.0 + esz) + (double)C * C * esz);
+                launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
+                                   w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,
+                                   a.larope_gamma, fs.pending ? &fs.fold : nullptr, 1, qb);
+                if (prof_on_) prof_end();
+                if (prof_on_) prof_begin("xattn_o", 2.0 * M * (double)C * C + 4.0 * M * (double)Lk * C, (double)M * C * (8.0 + esz) + (double)C * C * esz + (double)B * Lk * 2 * C * esz);
+                launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
+                                   w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,
+                                   a.larope_gamma, nullptr, 2, qb);
+                if (prof_on_) prof_end();
+                ar_.release(m2);
+                fs.pending = false;
+                return;
+            }
             if (prof_on_) prof_begin("xattn_fused", 4.0 * M * (double)C * C + 4.0 * M * (double)Lk * C, (double)M * C * 8.0 + 2.0 * C * C * esz + (double)B * Lk * 2 * C * esz);
             launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
                                w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,

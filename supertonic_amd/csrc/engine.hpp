@@ -170,7 +170,7 @@ class Engine {
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
     // cross-attention blocks of the estimator as ONE launch each (kernels_xattn.hip) instead of four
-    void set_fused_xattn(bool on) { fused_xattn_ = on; }
+    void set_fused_xattn(int mode) { fused_xattn_ = mode < 0 || mode > 2 ? 0 : mode; }  // 0: four launches, 1: one, 2: two (cut behind the q projection)
     // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
     // 4 = text encoder / duration predictor.  bf16 engines, widths 256 / 384 / 512 (ffn_fused_supported)
     // 8 = the estimator's blocks as K4-split (hidden dimension cut over 4 workgroups per 128-row slab, 16-bit partial sums folded
@@ -316,7 +316,7 @@ class Engine {
     // A captured graph holds raw pointers: everything it can have baked in is part of its key — the batch buffers (`gen`, bumped
     // by every reallocation), the weights (`wgen`, bumped by every load), the pinned staging the copy nodes read, the stream.
     struct GraphKey {
-        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false, xattn = false; int ffn = 0; int rows = 0, vrows = 0, trows = 0;
+        int B = 0, Lt = 0, L = 0, steps = 0; bool noise = false, ragged = false; int xattn = 0; int ffn = 0; int rows = 0, vrows = 0, trows = 0;
         uint64_t gen = 0, wgen = 0; const void* p0 = nullptr; const void* p1 = nullptr; const void* pin = nullptr; hipStream_t s = nullptr;
         bool operator==(const GraphKey& o) const {
             return B == o.B && Lt == o.Lt && L == o.L && steps == o.steps && noise == o.noise && ragged == o.ragged && xattn == o.xattn && ffn == o.ffn &&
@@ -352,7 +352,7 @@ class Engine {
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int64_t ffn_split_min_rows_ = 1;     // K4-split from this many rows on (with the slab staged through LDS one utterance gains too: 20.0 vs 21.4 us per block); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
-    bool fused_xattn_ = false;  // one launch per cross-attention block of the estimator (kernels_xattn.hip); STN_XATTN=<0|1> overrides
+    int fused_xattn_ = 0;  // cross-attention blocks of the estimator: 0 four launches, 1 one launch, 2 two launches (kernels_xattn.hip); STN_XATTN=<0|1|2> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }

@@ -246,7 +246,10 @@ extern "C" void stn_dbg_xa(unsigned long long* out) { (void)hipDeviceSynchronize
 #else
 #define XA_STAMP(i) do { } while (0)
 #endif
-template <int C, int DH, int MT, bool F16>
+// PART 0: the whole block in one launch.  PART 1 / PART 2: the same phases as two launches cut behind the q projection — part 1 (fold +
+// LayerNorm + q projection + rotation, 32-row tiles: twice the workgroups for the half of the block whose cost is rows) leaves the folded
+// rows in x and the rotated, scaled q rows in `qbuf`; part 2 (attention + output projection + residual) reads them back.
+template <int C, int DH, int MT, bool F16, int PART>
 __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           float eps, const uint16_t* __restrict__ Wq, const float* __restrict__ bq,
                                                           const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp, int ldk,
@@ -256,7 +259,8 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
                                                           const int* __restrict__ q_off, const int* __restrict__ k_off, int rope_mode,
                                                           float log_base, float gamma,
                                                           const uint16_t* __restrict__ fpart, int fS, int64_t fstride, const float* __restrict__ fb2,
-                                                          const float* __restrict__ fgamma, const float* __restrict__ frv, int frv_ld) {
+                                                          const float* __restrict__ fgamma, const float* __restrict__ frv, int frv_ld,
+                                                          uint16_t* __restrict__ qbuf) {
     constexpr int QT = MT * 32, H = C / DH, NTW = C / 128, HD2 = DH / 2, CH = HD2 / 8;
     constexpr int XSTR = C * 2 + 16;  // bytes per XS row (the +16 spreads a 16-lane ds_read_b128 group over all banks)
     constexpr int KSTR = DH * 2 + 16;
@@ -280,13 +284,14 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
     XA_STAMP(0);
     const int ncol0 = wave * NTW * 32;  // this wave's output columns in the two projections
     bf16x8_t bfr[XA_PD][NTW];
+    float4 keep[MT * 4][C / 128];  // this lane's share of the tile's residual rows (fp32), from here to the final store
+    if constexpr (PART != 2) {
     frag_prefetch<C, NTW>(Wq, ncol0, lane, bfr);  // the first four k-steps of Wq travel while the LayerNorm runs
 
     // ---- 0. (fold +) LayerNorm -> XS --------------------------------------------------------------------------------------
     // One row per HALF wavefront (32 lanes x 3 float4 slots = the 384 channels), two rows of each half in flight: every global
     // load of a pass is issued before the first use, the two LayerNorm reductions are 4 DPP steps + one swizzle (kernels_fold.hpp),
     // and nothing in the loop depends on a runtime "pointer or constant" choice (fold / time-vector presence are compile-time).
-    float4 keep[MT * 4][C / 128];  // this lane's share of the tile's residual rows (fp32), from here to the final store
     if (!fpart) xa_ln_phase<C, MT, F16, 0, false>(x, xrow0, nrows, XS, XSTR, ln_g, ln_b, eps, nullptr, 0, nullptr, nullptr, nullptr, tid, keep);
     else if (fS == 4 && frv) xa_ln_phase<C, MT, F16, 4, true>(x, xrow0, nrows, XS, XSTR, ln_g, ln_b, eps, fpart, fstride, fb2, fgamma, frv + (size_t)b * frv_ld, tid, keep);
     else if (fS == 4) xa_ln_phase<C, MT, F16, 4, false>(x, xrow0, nrows, XS, XSTR, ln_g, ln_b, eps, fpart, fstride, fb2, fgamma, nullptr, tid, keep);
@@ -361,6 +366,55 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
                 *reinterpret_cast<u32x4_t*>(p0) = o0;
                 *reinterpret_cast<u32x4_t*>(p0 + HD2 * 2) = o1;
             }
+    }
+
+    }  // PART != 2
+    if constexpr (PART == 1) {
+        __syncthreads();  // the rotated q tile is complete
+        // q rows out, whole rows (16 bytes per item, a row's 48 items on neighbouring threads)
+        constexpr int CPRW = C / 8;
+        for (int idx = tid; idx < nrows * CPRW; idx += 256) {
+            const int r = idx / CPRW, c = idx - r * CPRW;
+            *reinterpret_cast<u32x4_t*>(qbuf + (xrow0 + r) * C + c * 8) = *reinterpret_cast<const u32x4_t*>(XS + r * XSTR + c * 16);
+        }
+        if (fpart) {  // the folded rows (fp32) replace x: part 2 adds the block's output to them
+            const int l32 = lane & 31, hw = lane >> 5;
+#pragma unroll
+            for (int k = 0; k < MT * 4; ++k) {
+                const int r = 2 * wave + hw + 8 * k;
+                if (r < nrows) {
+#pragma unroll
+                    for (int i = 0; i < C / 128; ++i) reinterpret_cast<float4*>(x + (xrow0 + r) * C)[l32 + 32 * i] = keep[k][i];
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (PART == 2) {
+        // the residual rows this lane updates at the end (their loads stay in flight under the whole kernel) and the q tile
+        {
+            const int l32 = lane & 31, hw = lane >> 5;
+#pragma unroll
+            for (int k = 0; k < MT * 4; ++k) {
+                const int r = 2 * wave + hw + 8 * k;
+                const float4* x4 = reinterpret_cast<const float4*>(x + (xrow0 + (r < nrows ? r : 0)) * C);
+#pragma unroll
+                for (int i = 0; i < C / 128; ++i) keep[k][i] = x4[l32 + 32 * i];
+            }
+        }
+        constexpr int CPRW = C / 8, NQI = (QT * CPRW + 255) / 256;
+        u32x4_t qw[NQI];
+#pragma unroll
+        for (int i = 0; i < NQI; ++i) {
+            const int idx = tid + 256 * i, r = idx / CPRW, c = idx - r * CPRW;
+            qw[i] = *reinterpret_cast<const u32x4_t*>(qbuf + (xrow0 + (r < nrows ? r : 0)) * C + c * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NQI; ++i) {
+            const int idx = tid + 256 * i, r = idx / CPRW, c = idx - r * CPRW;
+            if (idx < QT * CPRW) *reinterpret_cast<u32x4_t*>(XS + r * XSTR + c * 16) = r < nrows ? qw[i] : u32x4_t{0u, 0u, 0u, 0u};
+        }
     }
 
     // ---- 2. attention.  SLOTS heads are staged at a time (K rows and V^T per slot); a task = (32-query tile, slot) and wave w
@@ -557,22 +611,23 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(float* __restrict__ x,
     XA_STAMP(15);
 }
 
-template <int C, int DH, int MT, bool F16>
+template <int C, int DH, int MT, bool F16, int PART>
 void launch_one(hipStream_t s, float* x, const float* ln_g, const float* ln_b, float eps, const void* Wq, const float* bq, const void* kp,
                 const void* vp, int ldk, const void* Wo, const float* bo, int B, int L, int Lk, int kc, const int* qlen, const int* klen,
-                const int* q_off, const int* k_off, int rope_mode, float log_base, float gamma, const FoldArgs* fold) {
+                const int* q_off, const int* k_off, int rope_mode, float log_base, float gamma, const FoldArgs* fold, void* qbuf) {
     constexpr int SLOTS = MT <= 2 ? 2 : 1;  // heads staged at a time (see the kernel)
     const size_t kv = SLOTS * ((size_t)kc * (DH * 2 + 16) + (size_t)DH * (kc * 2 + 8)), ys = (size_t)MT * 32 * (C + 4) * 4;  // K/V slots; the residual image (over everything)
-    const size_t lds = std::max((size_t)MT * 32 * (C * 2 + 16) + kv, ys);
+    const size_t lds = PART == 1 ? (size_t)MT * 32 * (C * 2 + 16) : std::max((size_t)MT * 32 * (C * 2 + 16) + kv, ys);
     static PerDeviceOnce attr_once;
     if (attr_once.need())
-        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<C, DH, MT, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024),
+        stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<C, DH, MT, F16, PART>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024),
                       "hipFuncSetAttribute(xattn_fused)");
     const dim3 grid((L + MT * 32 - 1) / (MT * 32), B);
-    STN_KLAUNCH((xattn_fused_kernel<C, DH, MT, F16>), grid, dim3(256), lds, s, x, ln_g, ln_b, eps, static_cast<const uint16_t*>(Wq), bq,
+    STN_KLAUNCH((xattn_fused_kernel<C, DH, MT, F16, PART>), grid, dim3(256), lds, s, x, ln_g, ln_b, eps, static_cast<const uint16_t*>(Wq), bq,
                 static_cast<const uint16_t*>(kp), static_cast<const uint16_t*>(vp), ldk, static_cast<const uint16_t*>(Wo), bo, L, Lk, kc, qlen,
                 klen, q_off, k_off, rope_mode, log_base, gamma, fold ? static_cast<const uint16_t*>(fold->part) : nullptr, fold ? fold->S : 0,
-                fold ? fold->part_stride : 0, fold ? fold->b2 : nullptr, fold ? fold->gamma : nullptr, fold ? fold->rowvec : nullptr, fold ? fold->rv_ld : 0);
+                fold ? fold->part_stride : 0, fold ? fold->b2 : nullptr, fold ? fold->gamma : nullptr, fold ? fold->rowvec : nullptr, fold ? fold->rv_ld : 0,
+                static_cast<uint16_t*>(qbuf));
 }
 
 }  // namespace
@@ -584,8 +639,9 @@ bool xattn_fused_supported(int dtype, int C, int H, int Lk, int ldk) {
 void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, const float* ln_b, float eps, const void* Wq, const float* bq,
                         const void* kp, const void* vp, int ldk, const void* Wo, const float* bo, int B, int L, int C, int H, int Lk,
                         const int* qlen, const int* klen, const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma,
-                        const FoldArgs* fold) {
+                        const FoldArgs* fold, int part, void* qbuf) {
     if (B == 0 || L == 0) return;
+    if (part < 0 || part > 2 || (part && (!qbuf || (reinterpret_cast<uintptr_t>(qbuf) & 15)))) throw std::invalid_argument("launch_xattn_fused: part 1 / 2 need a 16-byte aligned q buffer of rows x C");
     if (fold && (!fold->part || (fold->S != 4 && fold->S != 12 && fold->S != 24) || !fold->b2 || !fold->gamma || (fold->rowvec && fold->rv_ld % 4)))
         throw std::invalid_argument("launch_xattn_fused: the pending fold needs 16-bit partial sums of 4, 12 or 24 splits, b2 and gamma");
     if (!xattn_fused_supported(dtype, C, H, Lk, ldk) || (q_off && !qlen) || (k_off && !klen) || (reinterpret_cast<uintptr_t>(kp) & 15) ||
@@ -596,9 +652,19 @@ void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, c
     const long t32 = (long)B * ((L + 31) / 32), t64 = (long)B * ((L + 63) / 64);
     int mt = t32 <= 256 ? 1 : (t64 <= 768 ? 2 : 4);  // measured at B = 128, L = 78: 64-row tiles 15.5 ms per batch, 32- and 128-row tiles 16.2
     if (const char* f = getenv("STN_XATTN_MT")) mt = atoi(f) == 4 ? 4 : (atoi(f) == 2 ? 2 : 1);  // experiments
-#define STN_XA(MT_, F16_) launch_one<384, 96, MT_, F16_>(s, x, ln_g, ln_b, eps, Wq, bq, kp, vp, ldk, Wo, bo, B, L, Lk, kc, qlen, klen, q_off, k_off, rope_mode, lb, rope_gamma, fold)
-    if (dtype == F16) { if (mt == 1) STN_XA(1, true); else if (mt == 2) STN_XA(2, true); else STN_XA(4, true); }
-    else { if (mt == 1) STN_XA(1, false); else if (mt == 2) STN_XA(2, false); else STN_XA(4, false); }
+#define STN_XA(MT_, F16_, P_) launch_one<384, 96, MT_, F16_, P_>(s, x, ln_g, ln_b, eps, Wq, bq, kp, vp, ldk, Wo, bo, B, L, Lk, kc, qlen, klen, q_off, k_off, rope_mode, lb, rope_gamma, fold, qbuf)
+    if (part == 1) {  // rows only: 32-row tiles while they leave at most ~4 workgroups per CU, 64 beyond
+        if (t32 <= 1024) { if (dtype == F16) STN_XA(1, true, 1); else STN_XA(1, false, 1); }
+        else { if (dtype == F16) STN_XA(2, true, 1); else STN_XA(2, false, 1); }
+        return;
+    }
+    if (part == 2) {
+        if (dtype == F16) { if (mt == 1) STN_XA(1, true, 2); else if (mt == 2) STN_XA(2, true, 2); else STN_XA(4, true, 2); }
+        else { if (mt == 1) STN_XA(1, false, 2); else if (mt == 2) STN_XA(2, false, 2); else STN_XA(4, false, 2); }
+        return;
+    }
+    if (dtype == F16) { if (mt == 1) STN_XA(1, true, 0); else if (mt == 2) STN_XA(2, true, 0); else STN_XA(4, true, 0); }
+    else { if (mt == 1) STN_XA(1, false, 0); else if (mt == 2) STN_XA(2, false, 0); else STN_XA(4, false, 0); }
 #undef STN_XA
 }
 

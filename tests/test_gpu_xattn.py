@@ -47,6 +47,11 @@ def test_vector_est_fused_equals_unfused(dtype, tol, n, min_words, max_words):
     eng.set_fused_xattn(True)
     again = eng.vector_est(xt, te, sttl, mask, lm, tot, cur)
     assert np.array_equal(again, outs[True])
+    # the two-launch form (the same phases cut behind the q projection, 32-row tiles in the first half): the same bits
+    eng.set_fused_xattn(2)
+    two = eng.vector_est(xt, te, sttl, mask, lm, tot, cur)
+    assert np.array_equal(two, outs[True])
+    eng.set_fused_xattn(0)
 
 
 @pytest.mark.parametrize("dtype,tol_max,tol_rms", [("bf16", 3e-1, 5e-2), ("f16", 4e-2, 8e-3)])
@@ -81,3 +86,9 @@ def test_batch_pipeline_fused_vs_oracle_and_unfused(dtype, tol_max, tol_rms):
         w, _ = eng.batch_fetch()
         first = w.copy() if first is None else first
         assert np.array_equal(w, first)
+    eng.set_fused_xattn(2)  # two launches per block: the same bits, eager, captured and replayed
+    for _ in range(3):
+        eng.batch_run(3, 1.05, 1234)
+        w, _ = eng.batch_fetch()
+        assert np.array_equal(w, first)
+    eng.set_fused_xattn(0)
