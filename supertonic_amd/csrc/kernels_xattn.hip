@@ -44,11 +44,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    const unsigned ra = (ua + 0x7FFFu + ((ua >> 16) & 1u)) >> 16, rb = (ub + 0x7FFFu + ((ub >> 16) & 1u)) >> 16;
-    return ra | (rb << 16);
-}
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <bool F16>
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
@@ -71,11 +66,6 @@ template <bool F16>
 __device__ __forceinline__ f32x16_t mfma_h(bf16x8_t a, bf16x8_t b, f32x16_t c) {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 // acc[mt][nt] += XS[32*mt .. +32][:] . W[n0 + 32*nt .. +32][:]^T over K = C.  The weight arrives in FRAGMENT ORDER
