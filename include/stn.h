@@ -75,7 +75,8 @@ const char* stn_last_error(const stn_handle* h);
  * {"arch": {"te_heads": n, "dp_heads": n, "ve_heads": n}} (no "tensors" table: the graphs are still walked).
  * Accepted spellings of the layout: LayerNormalization as one node or decomposed (ReduceMean / Sub / Pow / ReduceMean / Add / Sqrt / Div / Mul /
  * Add), q / k / v projections separate or fused (3C or 2C rows + Split), pointwise convolutions as Conv k=1, MatMul(+Add) with Transposes around it
- * or Gemm, GELU as a node or written with Erf / Tanh.  VERIFIED ON GRAPHS THE TESTS EMIT (tests/onnx_graphs.py), not on the published files, which
+ * or Gemm, GELU as a node or written with Erf / Tanh, the vocoder's wave head as a projection or as a one-channel ConvTranspose with stride ==
+ * kernel == base_chunk_size (an overlapping transposed convolution is another head: refused with the node named).  VERIFIED ON GRAPHS THE TESTS EMIT (tests/onnx_graphs.py), not on the published files, which
  * are not available offline: for real assets the explicit stn_weight_map.json below is the documented path, and the walk says where a graph departs
  * from the layout. */
 int stn_load_dir(stn_handle* h, const char* onnx_dir);

@@ -35,6 +35,7 @@ struct Tok {
     int out = 0, in = 0, k = 1, dil = 1;
     bool transposed = false;      // LINEAR stored [in][out]
     int heads = 0;                // head count of the first 4-D Reshape constant between this token and the next one
+    bool bias_bcast = false;      // the bias is one value for all `out` outputs (one-channel ConvTranspose head)
     std::string out_name;         // SCALE: the value it produces (a decomposed LayerNorm's beta Add refers to it)
     bool norm_scale = false;      // SCALE whose input is a normalised value (x - mean) / sqrt(var + eps): the gamma of a decomposed LayerNorm
 };
@@ -95,6 +96,21 @@ std::vector<Tok> weighted_nodes(const Model& m, const std::string& file, std::st
                 } else if (k == 1) { t.kind = LINEAR; t.in = (int)cig; }
                 else { t.kind = CONVK; t.in = (int)cig; }
                 emit = true;
+            }
+        } else if (n.op_type == "ConvTranspose") {
+            // the wave head as a transposed 1-D convolution (north_star's spelling): weight [Cin][Cout / group][k].  With ONE output channel and
+            // stride == kernel (no overlap, no padding) frame t writes samples t*k .. t*k + k - 1 = W^T x_t + b: the frame -> chunk projection the
+            // engine's head kernel computes, weight [Cin][k] = the transposed linear form, the one bias value for every sample.
+            const Tensor* w = get(n, 1);
+            const auto all_are = [&](const char* key, int64_t want) { const auto* v = n.attr(key); if (!v) return true; for (int64_t x : *v) if (x != want) return false; return true; };
+            if (is_float(w) && w->dims.size() == 3 && w->dims[1] == 1 && n.attr_i("group", 1) == 1 && n.attr_i("strides", 1) == w->dims[2] &&
+                all_are("pads", 0) && all_are("dilations", 1) && all_are("output_padding", 0)) {
+                t.kind = LINEAR; t.w = w; t.b = get(n, 2); t.in = (int)w->dims[0]; t.out = (int)w->dims[2]; t.transposed = true; t.bias_bcast = true; emit = true;
+            } else {
+                t.kind = OTHER; t.w = w; emit = true;
+                t.where += " (weight " + dims_str(w) + ", stride " + std::to_string(n.attr_i("strides", 1)) +
+                           ": only a one-channel transposed convolution with stride == kernel, no padding — a frame -> chunk projection — is part of the layout; "
+                           "an overlapping one is a different vocoder head)";
             }
         } else if (n.op_type == "MatMul") {
             const Tensor *w1 = get(n, 1), *w0 = get(n, 0);
@@ -219,6 +235,7 @@ struct Parser {
         if (!p || p->kind != LINEAR || (out >= 0 && p->out != out) || (in >= 0 && p->in != in)) fail(name, std::string(kind_name(LINEAR)) + " " + shape(out, in));
         bind(name + ".w", p->w, p->transposed, *p);
         bind(name + ".b", p->b, false, *p);
+        if (p->bias_bcast && p->b) r.tensors[name + ".b"].broadcast = p->out;
         ++i;
         return *p;
     }
@@ -582,6 +599,7 @@ std::vector<float> fetch(const Bound& b, const std::string& canonical, int rows,
     const size_t n = (size_t)rows * cols;
     if (!b.t) return std::vector<float>(n, 0.f);
     std::vector<float> v = onnx::to_float(*b.t);
+    if (b.broadcast > 0 && v.size() == 1) v.assign((size_t)b.broadcast, v[0]);
     // a row block of a fused projection: the initializer holds rows_total x cols (1-D tensors, the biases: rows_total elements)
     const bool vec = rows == 1 && b.rows_total > 0;  // canonical vectors are [1][n]
     const int full_rows = b.rows_total ? (vec ? 1 : b.rows_total) : rows, full_cols = vec ? b.rows_total : cols;
@@ -602,7 +620,7 @@ std::vector<float> fetch_canonical(const Bound& b, const std::string& canonical)
     std::vector<int64_t> d;
     for (int64_t x : b.t->dims) if (x != 1) d.push_back(x);
     if (d.size() <= 1) {  // a vector (bias, LayerNorm parameter, scale) or a block of one
-        const int n = (int)b.t->numel();
+        const int n = b.broadcast > 0 && b.t->numel() == 1 ? b.broadcast : (int)b.t->numel();
         return fetch(b, canonical, 1, b.rows_total ? b.nrows : n);
     }
     int64_t rest = 1;

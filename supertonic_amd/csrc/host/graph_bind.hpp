@@ -25,6 +25,9 @@ struct Bound {
     // a fused projection (one MatMul for q|k|v or k|v, split afterwards): this tensor is rows [row0, row0 + rows) of the
     // initializer's `rows_total` canonical rows; rows_total == 0: the whole initializer
     int row0 = 0, rows_total = 0, nrows = 0;
+    // a one-element initializer standing for `broadcast` equal values (the bias of a one-channel ConvTranspose wave head: every sample of the
+    // frame gets the same bias); 0: no
+    int broadcast = 0;
     std::string from;                 // "<file>: node #i <op> '<name>' input '<initializer>'"
 };
 

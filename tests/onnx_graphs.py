@@ -21,11 +21,15 @@ class Graph:
                                                               Sqrt / Div / Mul gamma / Add beta (beta dropped in the last form)
          qkv  = "separate" | "fused"                          q, k, v projections separately, or one 3C (self) / 2C (context k|v) projection + Split
          pw   = "mixed" | "matmul_transpose"                  projections in four encodings by position, or always Transpose -> MatMul -> Add -> Transpose
-         gelu = "op" | "op_tanh" | "erf" | "tanh"             a Gelu node (approximate = none / tanh), or the Erf / Tanh formulas spelled out"""
+         gelu = "op" | "op_tanh" | "erf" | "tanh"             a Gelu node (approximate = none / tanh), or the Erf / Tanh formulas spelled out
+         head = "linear" | "convtranspose" | "convtranspose_overlap"
+                                                              the vocoder's wave head as a projection, or as a one-channel ConvTranspose with stride ==
+                                                              kernel == base_chunk_size (the same arithmetic: one bias value for the whole frame), or with
+                                                              kernel == 2 x stride (an overlap-add head: NOT the layout, the loader must say so)"""
 
     def __init__(self, stage, tensor, breaks, variants=None):
         self.stage, self.tensor, self.breaks = stage, tensor, breaks
-        self.var = dict(ln="node", qkv="separate", pw="mixed", gelu="op")
+        self.var = dict(ln="node", qkv="separate", pw="mixed", gelu="op", head="linear")
         self.var.update(variants or {})
         self.inits, self.nodes, self.n = [], [], 0
         self.cur = IO[stage][0][0]
@@ -247,7 +251,17 @@ def build_graph_dir(tmp, a, tensor, breaks=None, with_heads=True, tts_overrides=
     for i in range(a.vo_blocks):
         g.convnext(f"vo.blk{i}", a.vo_dim, a.vo_hidden, a.vo_kernel, a.vo_dilations[i])
     g.ln("vo.out_ln", a.vo_dim)
-    g.linear("vo.head", a.base_chunk_size, a.vo_dim)
+    if g.var["head"] == "linear":
+        g.linear("vo.head", a.base_chunk_size, a.vo_dim)
+    else:
+        cs = a.base_chunk_size
+        W, b = g.w("vo.head.w", (cs, a.vo_dim)), g.w("vo.head.b", (cs,))
+        kk = cs if g.var["head"] == "convtranspose" else 2 * cs
+        Wt = np.ascontiguousarray(W.T).reshape(a.vo_dim, 1, cs)  # ConvTranspose weight: [Cin][Cout / group][k]
+        if kk != cs:
+            Wt = np.concatenate([Wt, Wt], axis=2)
+        g.cur = g.op("ConvTranspose", [g.cur, g.init("vo.head", Wt), g.init("vo.head", b[:1])],
+                     [ow.attr_ints("kernel_shape", [kk]), ow.attr_ints("strides", [cs]), ow.attr_ints("pads", [0, 0] if kk == cs else [cs // 2, cs // 2])])
     graphs["vo"] = g
 
     for st, fn in FILES.items():

@@ -231,6 +231,31 @@ def test_exporter_variants_load_bit_identically(tmp_path, variants):
         assert "Tanh" in eng.last_error()
 
 
+def test_wave_head_as_transposed_convolution_loads_like_the_projection(tmp_path):
+    """The vocoder head written as a one-channel ConvTranspose (stride == kernel == base_chunk_size, north_star's spelling) is the frame -> chunk
+    projection with one bias value per frame: an engine loaded from such graphs equals, bit for bit, one loaded from graphs that spell the same
+    weights as a projection whose bias vector is that constant."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+
+    def flat_bias(name):
+        t = ref.tensor(name)
+        return np.full_like(t, t[0]) if name == "vo.head.b" else t
+
+    d1, d2 = tmp_path / "ct", tmp_path / "lin"
+    d1.mkdir(); d2.mkdir()
+    build_graph_dir(d1, a, ref.tensor, variants=dict(head="convtranspose"))
+    build_graph_dir(d2, a, flat_bias)
+    e1, e2 = binding.Engine(0, "f32"), binding.Engine(0, "f32")
+    e1.load_dir(str(d1)); e2.load_dir(str(d2))
+    assert e1.param_count == e2.param_count
+    ids, mask, sttl, sdp = make_inputs(a, 2, 12, [12, 7], seed=2)
+    durs = np.array([0.3, 0.12], np.float32)
+    w1, _ = e1.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=9)
+    w2, _ = e2.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=durs, noise_seed=9)
+    assert np.array_equal(w1, w2) and np.all(np.isfinite(w1)) and float(np.abs(w1).max()) > 0
+
+
 def test_missing_head_counts_are_an_error_until_stated(tmp_path):
     a = tiny_arch()
     ref = RefModel(a, 7)

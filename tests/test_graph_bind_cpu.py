@@ -132,6 +132,25 @@ def test_variant_values_reach_the_engine_layout(tmp_path):
         np.testing.assert_array_equal(got, ref.tensor(name), err_msg=name)
 
 
+def test_wave_head_as_a_one_channel_transposed_convolution(tmp_path):
+    """north_star's spelling of the vocoder head: ConvTranspose, one output channel, stride == kernel == base_chunk_size.  It is the frame -> chunk
+    projection (weight [Cin][1][k] = the transposed linear form) with ONE bias value for every sample of the frame; an overlapping transposed
+    convolution (kernel 2 x stride) is another head, and the loader says so."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    build_graph_dir(tmp_path, a, ref.tensor, variants=dict(head="convtranspose"))
+    g = host.bind_graphs(str(tmp_path))
+    for f in ARCH_FIELDS:
+        assert g["arch"][f] == getattr(a, f), f
+    assert "ConvTranspose" in g["tensors"]["vo.head.w"]["from"]
+    np.testing.assert_array_equal(host.bound_tensor(str(tmp_path), "vo.head.w"), ref.tensor("vo.head.w"))
+    b = host.bound_tensor(str(tmp_path), "vo.head.b")
+    assert b.shape == (a.base_chunk_size,) and np.all(b == ref.tensor("vo.head.b")[0])
+    build_graph_dir(tmp_path, a, ref.tensor, variants=dict(head="convtranspose_overlap"))
+    with pytest.raises(OSError, match=r"vocoder\.onnx.*vo\.head.*ConvTranspose.*stride == kernel"):
+        host.bind_graphs(str(tmp_path))
+
+
 @pytest.mark.parametrize("breaks,needle", [
     ({"vo.blk1": "width"}, r"vocoder\.onnx.*vo\.blk1\.dw = depthwise Conv over 64 channels.*the graph has depthwise Conv 72 <- 72.*node #\d+ Conv.*\[72,1,7\].*vo_blocks=1"),
     ({"te.conv1": "no_gamma"}, r"text_encoder\.onnx.*te\.conv1\.gamma = per-channel scale \(Mul\) over 64 channels; the graph has LayerNormalization"),
