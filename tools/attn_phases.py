@@ -1,5 +1,7 @@
 """Phase stamps of one workgroup of the MFMA attention kernel on the estimator's cross-attention shapes (measurement build:
-`make EXTRA=-DSTN_ATTN_STAMPS`).  Shader-clock cycles between: entry, Q staged, K staged, V staged + barrier, max pass, PV pass, stores."""
+`make EXTRA=-DSTN_ATTN_STAMPS`).  Shader-clock cycles between: entry, Q staged, K staged, V staged + barrier, max pass, PV pass, stores.
+Since round 3 the loads of Q, K and V are all issued before the first LDS store (one key chunk): "Q staged" holds the wait for ALL of them plus
+the Q rotation and stores, "K staged" / "V staged" only their arithmetic and LDS stores."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
