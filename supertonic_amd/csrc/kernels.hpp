@@ -139,6 +139,10 @@ int ffn_split_factor(int dtype, int C, int I);
 bool ffn_split_valid(int dtype, int C, int I, int S);
 int ffn_split_choose(int dtype, int C, int I, int64_t M);
 inline int64_t ffn_split_rows(int64_t M) { return (M + 127) / 128 * 128; }
+// K4's LDS layout, one definition for the kernel and its launcher: 4 ring buffers of C * 64 bytes | b2, gamma (C floats each) | b1 (I floats) |
+// at C = 384 a fifth buffer, KiB-aligned, for wave 0's rows of the slab in the prologue (kernels_ffn_body.inc)
+__host__ __device__ constexpr inline int ffn_lds_side_offset(int C, int I) { return (4 * C * 64 + (I + 2 * C) * 4 + 1023) & ~1023; }
+__host__ __device__ constexpr inline bool ffn_lds_has_side(int C) { return C == 384; }
 void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a);
 // The pending update of a K4-split launch, folded by the next reader of x:
 //   x_new[m] = x[m] + gamma * (((part[0][m] + part[1][m]) + part[2][m]) + ... + b2) + rowvec[seq(m)]      (fp32, this order)

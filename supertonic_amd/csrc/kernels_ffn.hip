@@ -264,7 +264,7 @@ void launch_ffn_pack(hipStream_t s, const void* W1, const void* W2, int C, int I
 // row images of 32 x (2C + 16) bytes
 static size_t ffn_lds_bytes(int C, int I) {
     size_t ring = (size_t)4 * C * 64 + (size_t)(I + 2 * C) * 4;
-    if (C == 384) ring = ((ring + 1023) & ~(size_t)1023) + (size_t)C * 64;  // a fifth buffer: wave 0's rows of the slab in the prologue (kernels_ffn_body.inc)
+    if (ffn_lds_has_side(C)) ring = (size_t)ffn_lds_side_offset(C, I) + (size_t)C * 64;  // a fifth buffer: wave 0's rows of the slab in the prologue (kernels.hpp)
     const size_t img = (size_t)4 * 32 * (C * 2 + 16);
     return ring > img ? ring : img;
 }
