@@ -102,13 +102,21 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the engine has no CPU fallback");
     if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
     STN_HIP(hipSetDevice(device));
-    STN_HIP(hipStreamCreateWithFlags(&own_s_, hipStreamNonBlocking));
+    // Stream priorities: the latent pipeline on the main stream at the highest priority, the two text stages on side streams beside it at the
+    // default one — where both have workgroups to place, the chain that bounds the batch goes first (11.59 -> 11.52 ms per batch, same box;
+    // STN_PRIO=<main><side>, each h / n / l, overrides: nn = both default)
+    int prio_least = 0, prio_greatest = 0;
+    STN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const char* pr = getenv("STN_PRIO");
+    auto prio_of = [&](char c) { return c == 'h' ? prio_greatest : c == 'l' ? prio_least : 0; };
+    const int prio_main = pr && pr[0] ? prio_of(pr[0]) : prio_greatest, prio_side = pr && pr[0] && pr[1] ? prio_of(pr[1]) : 0;
+    STN_HIP(hipStreamCreateWithPriority(&own_s_, hipStreamNonBlocking, prio_main));
     s_ = own_s_;
-    STN_HIP(hipStreamCreateWithFlags(&dp_s_, hipStreamNonBlocking));
+    STN_HIP(hipStreamCreateWithPriority(&dp_s_, hipStreamNonBlocking, prio_side));
     STN_HIP(hipEventCreateWithFlags(&ev_te_, hipEventDisableTiming));
     STN_HIP(hipEventCreateWithFlags(&ev_copied_, hipEventDisableTiming));
     STN_HIP(hipEventCreateWithFlags(&ev_dp_, hipEventDisableTiming));
-    STN_HIP(hipStreamCreateWithFlags(&te_s_, hipStreamNonBlocking));
+    STN_HIP(hipStreamCreateWithPriority(&te_s_, hipStreamNonBlocking, prio_side));
     if (const char* p = getenv("STN_DP_STREAM")) if (atoi(p) == 0) {  // A/B switch: everything on the main stream
         (void)hipStreamDestroy(dp_s_); dp_s_ = nullptr;
         (void)hipStreamDestroy(te_s_); te_s_ = nullptr;
