@@ -102,14 +102,14 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the engine has no CPU fallback");
     if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
     STN_HIP(hipSetDevice(device));
-    // Stream priorities: the latent pipeline on the main stream at the highest priority, the two text stages on side streams beside it at the
-    // default one — where both have workgroups to place, the chain that bounds the batch goes first (11.59 -> 11.52 ms per batch, same box;
-    // STN_PRIO=<main><side>, each h / n / l, overrides: nn = both default)
+    // Stream priorities, experiment switch STN_PRIO=<main><side>, each h / n / l (default nn: all streams at the default priority).  Measured:
+    // the main stream at the highest priority gains 0.6 % for one batch at a time (11.59 -> 11.52 ms) and LOSES a third of the rate with two
+    // handles in flight (53 k -> 34 k audio-s/s: two highest-priority queues no longer interleave) — not adopted
     int prio_least = 0, prio_greatest = 0;
     STN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     const char* pr = getenv("STN_PRIO");
     auto prio_of = [&](char c) { return c == 'h' ? prio_greatest : c == 'l' ? prio_least : 0; };
-    const int prio_main = pr && pr[0] ? prio_of(pr[0]) : prio_greatest, prio_side = pr && pr[0] && pr[1] ? prio_of(pr[1]) : 0;
+    const int prio_main = pr && pr[0] ? prio_of(pr[0]) : 0, prio_side = pr && pr[0] && pr[1] ? prio_of(pr[1]) : 0;
     STN_HIP(hipStreamCreateWithPriority(&own_s_, hipStreamNonBlocking, prio_main));
     s_ = own_s_;
     STN_HIP(hipStreamCreateWithPriority(&dp_s_, hipStreamNonBlocking, prio_side));

@@ -56,7 +56,7 @@ SWITCHES = [
     ("STN_FOLD_TCH", "8", "equal"),        # the fold kernel's run length: the same bits either way
     ("STN_FOLD_TCH", "32", "equal"),
     ("STN_DWCONV_XCD", "0", "equal"),      # tile order of the comb kernel: placement only
-    ("STN_PRIO", "nn", "equal"),           # stream priorities: scheduling only
+    ("STN_PRIO", "hn", "equal"),           # stream priorities: scheduling only
     ("STN_PRIO", "ll", "equal"),
     ("STN_FFN", "banana", "bound"),        # malformed: falls back to a documented value, never crashes
     ("STN_FFN_SPLIT_S", "5", "bound"),     # not a supported split: ignored
