@@ -40,7 +40,10 @@ def gelu(x):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 144, 384), (49, 384, 144), (1000, 512, 2048), (7, 1, 128),
                                    (257, 130, 72),
                                    # tiny M, long K: the deterministic split-K path (8 / 8 / 6 splits)
-                                   (49, 384, 1536), (128, 512, 2048), (64, 256, 1152)])
+                                   (49, 384, 1536), (128, 512, 2048), (64, 256, 1152),
+                                   # tiny products (one thread per output, gemm_tiny_f32_kernel): the duration predictor's style K/V projection
+                                   # and pooled layers, a single column, K not a multiple of 32
+                                   (1024, 256, 16), (128, 128, 128), (128, 1, 128), (5, 7, 20), (64, 512, 256)])
 def test_gemm_f32(eng, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -131,7 +134,9 @@ def test_dwconv_ln(eng, C, k, dil, B, L):
 @pytest.mark.parametrize("dh,H,Lq,Lk,rope", [(32, 2, 7, 11, -1), (64, 4, 70, 70, 0), (96, 4, 49, 62, 1), (48, 2, 33, 130, 1),
                                               (16, 2, 5, 6, 0), (64, 4, 200, 310, 0), (96, 2, 130, 50, -1), (32, 4, 129, 33, 1),
                                               # long contexts: keys stream through LDS in 128-key chunks (3 chunks here), partial last chunk
-                                              (96, 4, 78, 311, 1), (96, 2, 140, 257, 0), (32, 2, 40, 129, -1)])
+                                              (96, 4, 78, 311, 1), (96, 2, 140, 257, 0), (32, 2, 40, 129, -1),
+                                              # a handful of keys, no rotation (fp32: attn_fewkeys_f32_kernel; the duration predictor's 8 style tokens)
+                                              (64, 2, 70, 8, -1), (96, 1, 130, 16, -1), (16, 2, 5, 6, -1), (64, 2, 300, 1, -1)])
 def test_attention(eng, dh, H, Lq, Lk, rope):
     rng = np.random.default_rng(dh + Lq + Lk)
     B, C = 2, dh * H
