@@ -1,5 +1,6 @@
 // engine.cpp — weights, workspace and the four stage executors (see engine.hpp).
 #include "engine.hpp"
+#include "engine_internal.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -7,6 +8,7 @@
 #include <cstring>
 
 namespace stn {
+using detail::up;
 
 // =================================================================================================
 // Arena
@@ -1100,14 +1102,6 @@ void Engine::vocoder_dev(int B, int L, const float* latent, float* wav, const in
 // =================================================================================================
 // host-pointer stages (the four former Run sites)
 // =================================================================================================
-namespace {
-template <typename T>
-T* up(Arena& ar, hipStream_t s, const T* h, size_t n) {
-    T* d = static_cast<T*>(ar.alloc(n * sizeof(T)));
-    STN_HIP(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s));
-    return d;
-}
-}  // namespace
 
 void Engine::duration(int B, int Lt, const int64_t* ids, const float* style_dp, const float* text_mask, float* dur) {
     STN_HIP(hipSetDevice(device_));
@@ -1173,883 +1167,6 @@ void Engine::vocoder(int B, int L, const float* latent, float* wav) {
     float* d_wav = f32_alloc(nw);
     vocoder_dev(B, L, d_lat, d_wav);
     STN_HIP(hipMemcpyAsync(wav, d_wav, nw * 4, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-// =================================================================================================
-// resident batch
-// =================================================================================================
-namespace {
-}  // namespace
-
-// Grow-only device buffer of the resident batch.  A reallocation retires the old block (freed at the next upload, once the
-// stream has drained) and bumps the generation that is part of the graph key: a captured graph holds raw pointers.
-template <typename T>
-void Engine::ensure(T*& p, size_t& cap, size_t need) {
-    if (p && need <= cap) return;
-    const size_t n = std::max<size_t>(need + need / 4, 64);  // headroom: ragged request streams settle after a few uploads
-    T* q = nullptr;
-    STN_HIP(hipMalloc(reinterpret_cast<void**>(&q), n * sizeof(T)));
-    if (p) {
-        batch_owned_.erase(std::find(batch_owned_.begin(), batch_owned_.end(), static_cast<void*>(p)));
-        batch_retired_.push_back(p);
-    }
-    batch_owned_.push_back(q);
-    p = q;
-    cap = n;
-    ++bt_.gen;
-}
-
-void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_mask, const float* style_ttl,
-                          const float* style_dp, const float* duration_override, const int64_t* utt_ids) {
-    STN_HIP(hipSetDevice(device_));
-    if (!loaded_) throw std::runtime_error("no model loaded");
-    if (B <= 0 || Lt <= 0) throw std::runtime_error("empty batch");
-    sync();
-    for (void* p : batch_retired_) (void)hipFree(p);
-    batch_retired_.clear();
-    Batch& b = bt_;
-    b.B = B; b.Lt = Lt; b.L = 0; b.noise_L = 0; b.total_step = 0;
-    b.have_override = false; b.have_noise = false;
-    b.h_dur.clear(); b.h_llen.clear();
-    const size_t n_ttl = (size_t)B * a_.n_style_ttl * a_.d_style_ttl, n_dp = (size_t)B * a_.n_style_dp * a_.d_style_dp;
-    ensure(b.ids, b.ids_cap, (size_t)B * Lt);
-    ensure(b.tlen, b.tlen_cap, (size_t)B);
-    ensure(b.style_ttl, b.ttl_cap, n_ttl);
-    ensure(b.style_dp, b.dp_cap, n_dp);
-    ensure(b.dur, b.dur_cap, (size_t)B);
-    ensure(b.llen, b.llen_cap, (size_t)B);
-    ensure(b.utt_ids, b.utt_cap, (size_t)B);
-    STN_HIP(hipMemcpyAsync(b.ids, ids, sizeof(int64_t) * B * Lt, hipMemcpyHostToDevice, s_));
-    STN_HIP(hipMemcpyAsync(b.style_ttl, style_ttl, sizeof(float) * n_ttl, hipMemcpyHostToDevice, s_));
-    STN_HIP(hipMemcpyAsync(b.style_dp, style_dp, sizeof(float) * n_dp, hipMemcpyHostToDevice, s_));
-    std::vector<int64_t> uid(B);
-    for (int i = 0; i < B; ++i) uid[i] = utt_ids ? utt_ids[i] : i;
-    STN_HIP(hipMemcpyAsync(b.utt_ids, uid.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s_));
-    ar_.reset();
-    float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt);
-    launch_mask_to_len(s_, d_mask, B, Lt, b.tlen);
-    // packed text rows: first row of each utterance (fixed for the life of this upload) and their total
-    ensure(b.toff, b.toff_cap, (size_t)B + 1);
-    b.trows = 0;
-    for (int i = 0; i < B; ++i) {
-        int n = 0;
-        for (int t = 0; t < Lt; ++t) n += text_mask[(size_t)i * Lt + t] > 0.5f ? 1 : 0;  // as mask_to_len_kernel counts
-        b.trows += n;
-    }
-    if (B <= 1024) launch_row_map(s_, b.tlen, B, b.toff, nullptr);
-    b.have_override = duration_override != nullptr;
-    if (duration_override) b.h_dur.assign(duration_override, duration_override + B);
-    sync();
-}
-
-void Engine::batch_set_noise(const float* noise, int L) {
-    STN_HIP(hipSetDevice(device_));
-    Batch& b = bt_;
-    if (b.B == 0) throw std::runtime_error("batch_set_noise: no batch uploaded");
-    if (L < 1) throw std::runtime_error("batch_set_noise: L must be >= 1");
-    const int D = a_.latent_dim * a_.chunk_compress_factor;
-    sync();
-    ensure(b.noise, b.noise_cap, (size_t)b.B * D * L);
-    STN_HIP(hipMemcpyAsync(b.noise, noise, sizeof(float) * b.B * D * L, hipMemcpyHostToDevice, s_));
-    b.have_noise = true;
-    b.noise_L = L;  // checked against the durations in batch_run
-    sync();
-}
-
-// Latent geometry exactly as TextToSpeech::sampleNoisyLatent (/root/reference/cpp/helper.cpp:424-440,457,764-768):
-// float32 products, truncation to integers.
-static void latent_geometry(const stn_arch& a, const std::vector<float>& dur, int& L, std::vector<int>& llen) {
-    const int cs = a.base_chunk_size * a.chunk_compress_factor;
-    float mx = dur[0];
-    for (float d : dur) mx = std::max(mx, d);
-    const float wav_len_max = mx * (float)a.sample_rate;
-    L = (int)((wav_len_max + (float)cs - 1.0f) / (float)cs);
-    llen.resize(dur.size());
-    for (size_t i = 0; i < dur.size(); ++i) {
-        const int64_t wl = (int64_t)(dur[i] * (float)a.sample_rate);
-        llen[i] = (int)((wl + cs - 1) / cs);
-    }
-}
-
-void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
-    STN_HIP(hipSetDevice(device_));
-    Batch& b = bt_;
-    if (b.B == 0) throw std::runtime_error("batch_run: no batch uploaded");
-    if (total_step < 1) throw std::runtime_error("total_step must be >= 1");
-    if (!(speed > 0.f)) throw std::runtime_error("speed must be > 0");
-    const stn_arch& a = a_;
-    const int B = b.B, Lt = b.Lt, D = a.latent_dim * a.chunk_compress_factor;
-    b.total_step = total_step; b.speed = speed; b.noise_seed = noise_seed;
-    ar_.reset();
-    // 1. duration predictor (always executed; its output may be overridden for shape control)
-    Ragged trg;
-    const bool tpk = packed_text_ok(B) && b.trows > 0;
-    if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
-    std::vector<float> dur(B);
-    // the text rows: persistent, grow-only buffers (a reallocation bumps b.gen, which every graph key holds)
-    const size_t text_bytes = (size_t)(tpk ? (int64_t)b.trows : (int64_t)B * Lt) * a.te_out_dim * (is_half(dt_) ? 2 : 4);
-    ensure(b.text_side, b.text_side_cap, text_bytes);
-    ensure(b.text_rows, b.text_cap, text_bytes);
-    {
-        // on the side streams, each with its own workspace (see dp_s_): swapped in for the duration of a text stage
-        struct Side {
-            Engine& e; hipStream_t& s; Arena& ar; bool on;
-            Side(Engine& e_, hipStream_t& s_, Arena& ar_) : e(e_), s(s_), ar(ar_), on(s_ != nullptr) { if (on) { std::swap(e.s_, s); e.ar_.swap(ar); e.ar_.reset(); } }
-            ~Side() { if (on) { std::swap(e.s_, s); e.ar_.swap(ar); } }
-        };
-        {   // 2. text encoder -> context rows (act dtype), once the previous run has taken its copy of them
-            Side side(*this, te_s_, te_ar_);
-            if (side.on && copied_valid_) STN_HIP(hipStreamWaitEvent(s_, ev_copied_, 0));
-            text_enc_dev(B, Lt, b.ids, b.style_ttl, b.tlen, nullptr, b.text_side, tpk ? &trg : nullptr);
-            STN_HIP(hipEventRecord(ev_te_, s_));
-        }
-        {   // 1. duration predictor (always executed; its output may be overridden for shape control), beside the encoder
-            Side side(*this, dp_s_, dp_ar_);
-            duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
-            if (!b.have_override) {
-                STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
-                STN_HIP(hipEventRecord(ev_dp_, s_));
-            }
-        }
-        if (b.have_override) dur = b.h_dur;  // known on the host: no device->host read, no sync
-        else STN_HIP(hipEventSynchronize(ev_dp_));  // the one host round trip (the predictor only): L = f(max duration) sizes every later buffer
-    }
-    // Hand-over of this run's text rows to the main pipeline (everything captured below reads b.text_rows).  It happens where the
-    // rows are first needed — in front of the text K/V GEMM of the first text cross-attention — so the noise, the style K/V, the time
-    // conditioning and the first ConvNeXt blocks of the estimator run beside the encoder; a captured pipeline is therefore TWO
-    // graphs with this hand-over between them.
-    auto take_text_rows = [this, &b, text_bytes]() {
-        if (te_s_) STN_HIP(hipStreamWaitEvent(s_, ev_te_, 0));
-        STN_HIP(hipMemcpyAsync(b.text_rows, b.text_side, text_bytes, hipMemcpyDeviceToDevice, s_));
-        STN_HIP(hipEventRecord(ev_copied_, s_));
-        copied_valid_ = true;
-    };
-    for (float& d : dur) d /= speed;  // cpp/helper.cpp:529-531
-    int L = 0;
-    latent_geometry(a, dur, L, b.h_llen);
-    if (L < 1) throw std::runtime_error("predicted duration too short: zero latent frames");
-    if (b.have_noise && b.noise_L != L)
-        throw std::runtime_error("injected noise has L=" + std::to_string(b.noise_L) + " but the durations imply L=" + std::to_string(L));
-    b.L = L;
-    reported_dur_ = dur;  // durations after /speed: what the reference returns (cpp/helper.cpp:680)
-    const size_t nx = (size_t)B * D * L, nw = (size_t)B * L * a.base_chunk_size * a.chunk_compress_factor;
-    ensure(b.xt[0], b.xt_cap[0], nx);
-    ensure(b.xt[1], b.xt_cap[1], nx);
-    ensure(b.wav, b.wav_cap, nw);
-    // per-call data of the captured region lives in pinned host memory (the graph's memcpy nodes re-read it at replay).
-    // Sized for 1024 utterances up front so that it is not reallocated under cached graphs; should it ever have to grow, its
-    // address is part of the graph key and the graphs that point at the old block are dropped before it is freed.
-    if ((size_t)B > pin_llen_cap_) {
-        if (pin_llen_) { sync(); drop_graphs(); (void)hipHostFree(pin_llen_); pin_llen_ = nullptr; }
-        const size_t cap = std::max<size_t>((size_t)B, 1024);
-        STN_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin_llen_), sizeof(int) * cap, hipHostMallocDefault));
-        pin_llen_cap_ = cap;
-        pin_valid_ = false;
-    }
-    if (!pin_seed_) {
-        STN_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin_seed_), sizeof(unsigned long long), hipHostMallocDefault));
-        STN_HIP(hipMalloc(reinterpret_cast<void**>(&seed_dev_), sizeof(unsigned long long)));
-        pin_valid_ = false;
-    }
-    // a previous run's copy nodes may still be reading the staging: rewrite it only when the content changes, and then
-    // only after the stream has drained (steady-state replays of an unchanged batch never wait here)
-    if (!pin_valid_ || !std::equal(b.h_llen.begin(), b.h_llen.end(), pin_llen_) || *pin_seed_ != (unsigned long long)noise_seed) {
-        sync();
-        std::copy(b.h_llen.begin(), b.h_llen.end(), pin_llen_);
-        *pin_seed_ = (unsigned long long)noise_seed;
-        pin_valid_ = true;
-    }
-
-    GraphKey key;
-    key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.xattn = fused_xattn_;
-    key.ffn = fused_ffn_; key.gen = b.gen; key.wgen = wgen_; key.pin = pin_llen_;
-    key.rows = 0;
-    if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;
-    last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L;
-    key.vrows = trimmed_rows(B, L, nullptr);
-    key.trows = tpk ? b.trows : 0;
-    last_vo_rows_ = (int64_t)B * L * a.chunk_compress_factor;
-    if (vo_ragged_ && packed_ve_ && is_half(dt_)) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
-    else if (key.vrows) last_vo_rows_ = key.vrows;
-    key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
-    // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
-    const bool graphable = graph_on_ && !prof_on_;
-    if (graphable) {
-        for (auto& g : graphs_)
-            if (g.key == key) {
-                g.last_use = ++graph_clock_;
-                STN_HIP(hipGraphLaunch(g.exec, s_));
-                take_text_rows();
-                STN_HIP(hipGraphLaunch(g.exec2, s_));
-                ++graph_replays_;
-                return;
-            }
-    }
-    const auto warm = std::find(warm_keys_.begin(), warm_keys_.end(), key);
-    if (graphable && warm != warm_keys_.end()) {  // second sighting of this shape: the arena is warm, allocation order is fixed
-        const Arena::Mark cap0 = ar_.mark();
-        const size_t cap_before = ar_.capacity();
-        STN_HIP(hipStreamBeginCapture(s_, hipStreamCaptureModeThreadLocal));
-        bool ok = true;
-        std::string why;
-        hipGraph_t g = nullptr, g2 = nullptr;
-        hipError_t ec1 = hipErrorUnknown;
-        bool split = false;
-        // at the hand-over the first graph ends and the second begins (the hand-over itself is issued between their launches)
-        auto split_capture = [&]() {
-            ec1 = hipStreamEndCapture(s_, &g);
-            split = true;
-            STN_HIP(hipStreamBeginCapture(s_, hipStreamCaptureModeThreadLocal));
-        };
-        try { enqueue_after_duration(total_step, split_capture); } catch (const std::exception& e) { ok = false; why = e.what(); }
-        const hipError_t ec = hipStreamEndCapture(s_, &g2);
-        text_gate_ = nullptr;
-        ar_.release(cap0);
-        hipGraphExec_t ex = nullptr, ex2 = nullptr;
-        if (ok && split && ec1 == hipSuccess && ec == hipSuccess && g && g2 && ar_.capacity() == cap_before &&
-            hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && hipGraphInstantiate(&ex2, g2, nullptr, nullptr, 0) == hipSuccess) {
-            if (graphs_.size() >= kGraphCache) {  // evict the least recently used entry
-                auto lru = std::min_element(graphs_.begin(), graphs_.end(), [](const GraphEntry& x, const GraphEntry& y) { return x.last_use < y.last_use; });
-                sync();  // its last replay may still be running
-                (void)hipGraphExecDestroy(lru->exec);
-                (void)hipGraphDestroy(lru->graph);
-                if (lru->exec2) (void)hipGraphExecDestroy(lru->exec2);
-                if (lru->graph2) (void)hipGraphDestroy(lru->graph2);
-                graphs_.erase(lru);
-            }
-            GraphEntry e;
-            e.key = key; e.graph = g; e.exec = ex; e.graph2 = g2; e.exec2 = ex2; e.last_use = ++graph_clock_;
-            graphs_.push_back(e);
-            warm_keys_.erase(warm);
-            STN_HIP(hipGraphLaunch(ex, s_));
-            take_text_rows();
-            STN_HIP(hipGraphLaunch(ex2, s_));
-            ++graph_replays_;
-            return;
-        }
-        if (ex) (void)hipGraphExecDestroy(ex);
-        if (ex2) (void)hipGraphExecDestroy(ex2);
-        if (g2) (void)hipGraphDestroy(g2);
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        if (!ok) throw std::runtime_error("graph capture failed: " + why);
-        // fall through to an eager run
-    }
-    if (warm == warm_keys_.end()) {
-        if (warm_keys_.size() >= kWarmKeys) warm_keys_.erase(warm_keys_.begin());
-        warm_keys_.push_back(key);
-    }
-    enqueue_after_duration(total_step, take_text_rows);
-}
-
-// Everything after the duration read: lengths to the device, text encoder, initial latent, Euler loop, vocoder.
-void Engine::enqueue_after_duration(int total_step, const std::function<void()>& take_text_rows) {
-    Batch& b = bt_;
-    const stn_arch& a = a_;
-    const int B = b.B, Lt = b.Lt, L = b.L, D = a.latent_dim * a.chunk_compress_factor;
-    const size_t nx = (size_t)B * D * L;
-    STN_HIP(hipMemcpyAsync(b.llen, pin_llen_, sizeof(int) * B, hipMemcpyHostToDevice, s_));
-    STN_HIP(hipMemcpyAsync(seed_dev_, pin_seed_, sizeof(unsigned long long), hipMemcpyHostToDevice, s_));
-    // 2. (the text encoder ran on the side stream: batch_run) its rows
-    Ragged trg;
-    const bool tpk = packed_text_ok(B) && b.trows > 0;
-    if (tpk) { trg.off = b.toff; trg.rows = b.trows; }
-    const Ragged* trgp = tpk ? &trg : nullptr;
-    void* text_rows = b.text_rows;
-    // 3. initial latent
-    if (b.have_noise) {
-        STN_HIP(hipMemcpyAsync(b.xt[0], b.noise, nx * 4, hipMemcpyDeviceToDevice, s_));
-        launch_mask_ncl(s_, b.xt[0], B, D, L, b.llen);
-    } else {
-        launch_randn_masked(s_, 0, b.utt_ids, B, D, L, b.llen, b.xt[0], seed_dev_);
-    }
-    // 4. Euler loop: step-invariant K/V once, the time conditioning of every step in one pass, then total_step passes
-    VeCtx c = ve_prepare_dev(B, Lt, text_rows, b.style_ttl, b.tlen, trgp, /*defer_text=*/true);
-    // armed here, fired by the first text cross-attention of the first Euler step (ve_step_dev): hand-over of the rows, then the text K/V
-    text_gate_ = [this, &c, &b, &take_text_rows, B, Lt, text_rows, trgp]() {
-        take_text_rows();
-        ve_text_kv_dev(c, B, Lt, text_rows, b.tlen, trgp);
-    };
-    struct Disarm { std::function<void()>& g; ~Disarm() { g = nullptr; } } disarm{text_gate_};  // it refers to this frame: never outlives it
-    if (a.ve_main_blocks == 0) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }  // (no cross-attention would ever fire it)
-    float* tot_all = f32_alloc((int64_t)total_step * B);
-    float* cur_all = f32_alloc((int64_t)total_step * B);
-    float* dt_all = f32_alloc(B);
-    launch_step_counters(s_, tot_all, cur_all, dt_all, B, total_step);
-    const float* tb_all = ve_time_cond_dev(total_step * B, tot_all, cur_all);
-    const size_t tb_stride = (size_t)B * a.ve_main_blocks * a.ve_dim;
-    Ragged rg;
-    const Ragged* rgp = nullptr;
-    if (packed_rows_ok(B)) {  // the estimator works on the frames the utterances own and nothing else
-        rg.rows = 0;
-        for (int v : b.h_llen) rg.rows += v;
-        int* off = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)(B + 1)));
-        int* row_b = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)std::max(rg.rows, 1)));
-        launch_row_map(s_, b.llen, B, off, row_b);
-        rg.off = off; rg.row_b = row_b;
-        rgp = &rg;
-    }
-    int cur = 0;
-    for (int st = 0; st < total_step; ++st) {
-        ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, tot_all + (size_t)st * B, cur_all + (size_t)st * B, b.xt[cur ^ 1],
-                    tb_all + (size_t)st * tb_stride, rgp, dt_all);
-        cur ^= 1;
-    }
-    final_xt_ = cur;
-    // 5. vocoder
-    const int* vlen = nullptr;
-    if (vo_ragged_) {
-        int* v = static_cast<int*>(ar_.alloc(sizeof(int) * B));
-        launch_scale_len(s_, b.llen, B, a.chunk_compress_factor, v);
-        vlen = v;
-    }
-    int vrows = 0;
-    const int* valid = nullptr;
-    if (vo_ragged_ && packed_ve_) {
-        for (int v : b.h_llen) vrows += v * a.chunk_compress_factor;
-    } else if (const int tr = trimmed_rows(B, L, nullptr)) {
-        // reference (dense) semantics at the cost of the frames that are not position-independent
-        int* n_dev = static_cast<int*>(ar_.alloc(sizeof(int) * B));
-        int* v_dev = static_cast<int*>(ar_.alloc(sizeof(int) * B));
-        launch_trim_len(s_, b.llen, B, a.chunk_compress_factor, L * a.chunk_compress_factor, vo_rf_, n_dev, v_dev);
-        vlen = n_dev; valid = v_dev; vrows = tr;
-    }
-    vocoder_dev(B, L, b.xt[cur], b.wav, vlen, vrows, valid);
-    STN_HIP(hipGetLastError());  // a kernel launch that was rejected (bad configuration) must not pass silently
-}
-
-void Engine::batch_fetch(float* wav, size_t wav_capacity, float* duration) {
-    Batch& b = bt_;
-    const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
-    if (wav) {
-        if (wav_capacity < nw) throw std::runtime_error("wav buffer too small: need " + std::to_string(nw) + " floats");
-        STN_HIP(hipMemcpyAsync(wav, b.wav, nw * 4, hipMemcpyDeviceToHost, s_));
-    }
-    sync();
-    if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
-}
-void Engine::batch_fetch_pcm16(int16_t* pcm, size_t capacity, float* duration) {
-    STN_HIP(hipSetDevice(device_));
-    Batch& b = bt_;
-    const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
-    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
-    if (capacity < nw) throw std::runtime_error("pcm buffer too small: need " + std::to_string(nw) + " samples");
-    ensure(b.pcm, b.pcm_cap, nw);
-    launch_f32_to_pcm16(s_, b.wav, (int64_t)b.B, (int)(nw / (size_t)b.B), b.pcm, (int64_t)(nw / (size_t)b.B));
-    STN_HIP(hipMemcpyAsync(pcm, b.pcm, nw * 2, hipMemcpyDeviceToHost, s_));
-    sync();
-    if (duration) std::copy(reported_dur_.begin(), reported_dur_.end(), duration);
-}
-void Engine::batch_fetch_pcm16_begin(int slot) {
-    STN_HIP(hipSetDevice(device_));
-    if (slot < 0 || slot > 1) throw std::invalid_argument("fetch slot must be 0 or 1");
-    Batch& b = bt_;
-    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
-    const size_t nw = (size_t)b.B * b.L * a_.base_chunk_size * a_.chunk_compress_factor;
-    FetchSlot& f = fetch_[slot];
-    if (!copy_s_) STN_HIP(hipStreamCreateWithFlags(&copy_s_, hipStreamNonBlocking));
-    if (!f.ready) { STN_HIP(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming)); STN_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming)); }
-    if (f.busy) STN_HIP(hipEventSynchronize(f.done));  // the slot's previous copy (two batches ago) must be out before it is refilled
-    if (nw > f.cap) {
-        if (f.dev) (void)hipFree(f.dev);
-        if (f.pin) (void)hipHostFree(f.pin);
-        f.dev = nullptr; f.pin = nullptr;
-        const size_t cap = nw + nw / 4;
-        STN_HIP(hipMalloc(reinterpret_cast<void**>(&f.dev), cap * sizeof(int16_t)));
-        STN_HIP(hipHostMalloc(reinterpret_cast<void**>(&f.pin), cap * sizeof(int16_t), hipHostMallocDefault));
-        f.cap = cap;
-    }
-    launch_f32_to_pcm16(s_, b.wav, (int64_t)b.B, (int)(nw / (size_t)b.B), f.dev, (int64_t)(nw / (size_t)b.B));
-    STN_HIP(hipEventRecord(f.ready, s_));
-    STN_HIP(hipStreamWaitEvent(copy_s_, f.ready, 0));
-    STN_HIP(hipMemcpyAsync(f.pin, f.dev, nw * sizeof(int16_t), hipMemcpyDeviceToHost, copy_s_));
-    STN_HIP(hipEventRecord(f.done, copy_s_));
-    f.n = nw;
-    f.dur = reported_dur_;
-    f.busy = true;
-}
-void Engine::batch_fetch_pcm16_end(int slot, const int16_t** pcm, size_t* n, float* duration) {
-    if (slot < 0 || slot > 1) throw std::invalid_argument("fetch slot must be 0 or 1");
-    FetchSlot& f = fetch_[slot];
-    if (!f.busy) throw std::runtime_error("no fetch in flight on this slot");
-    STN_HIP(hipEventSynchronize(f.done));
-    if (pcm) *pcm = f.pin;
-    if (n) *n = f.n;
-    if (duration) std::copy(f.dur.begin(), f.dur.end(), duration);
-}
-void Engine::batch_copy_wav_device(float* dst, int64_t dst_stride) {
-    Batch& b = bt_;
-    const size_t W = (size_t)b.L * a_.base_chunk_size * a_.chunk_compress_factor;
-    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
-    if ((size_t)dst_stride < W) throw std::invalid_argument("dst_stride smaller than the waveform length");
-    STN_HIP(hipMemcpy2DAsync(dst, (size_t)dst_stride * 4, b.wav, W * 4, W * 4, (size_t)b.B, hipMemcpyDeviceToDevice, s_));
-}
-void Engine::batch_copy_pcm16_device(int16_t* dst, int64_t dst_stride) {
-    STN_HIP(hipSetDevice(device_));
-    Batch& b = bt_;
-    const size_t W = (size_t)b.L * a_.base_chunk_size * a_.chunk_compress_factor;
-    if (!b.wav || b.L == 0) throw std::runtime_error("no finished batch");
-    if ((size_t)dst_stride < W) throw std::invalid_argument("dst_stride smaller than the waveform length");
-    launch_f32_to_pcm16(s_, b.wav, (int64_t)b.B, (int)W, dst, dst_stride);
-}
-void Engine::batch_fetch_latent(float* latent) {
-    Batch& b = bt_;
-    const size_t nx = (size_t)b.B * a_.latent_dim * a_.chunk_compress_factor * b.L;
-    STN_HIP(hipMemcpyAsync(latent, b.xt[final_xt_], nx * 4, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-// =================================================================================================
-// op-level test entry points
-// =================================================================================================
-void Engine::op_gemm(int dtype, int M, int N, int K, const float* A, const float* W, const float* bias, int act, float* out) {
-    STN_HIP(hipSetDevice(device_));
-    ar_.reset();
-    float* dA = up(ar_, s_, A, (size_t)M * K);
-    float* dW = up(ar_, s_, W, (size_t)N * K);
-    float* dB = bias ? up(ar_, s_, bias, (size_t)N) : nullptr;
-    float* dO = f32_alloc((size_t)M * N);
-    const void* pa = dA;
-    const void* pw = dW;
-    if (is_half(dtype)) {
-        void* a16 = ar_.alloc((size_t)M * K * 2);
-        void* w16 = ar_.alloc((size_t)N * K * 2);
-        launch_cast(s_, dtype, dA, (int64_t)M * K, a16);
-        launch_cast(s_, dtype, dW, (int64_t)N * K, w16);
-        pa = a16; pw = w16;
-    }
-    Epilogue e; e.mode = EPI_STORE; e.act = act; e.out_dtype = F32; e.out = dO; e.ldo = N; e.bias = dB;
-    const int sk = gemm_splitk_factor(dtype, M, N, K, e);  // the same decision the model path takes (Engine::gemm)
-    if (sk > 1) launch_gemm_splitk(s_, dtype, pa, K, pw, K, M, N, K, e, sk, f32_alloc((int64_t)sk * M * N));
-    else launch_gemm(s_, dtype, pa, K, pw, K, M, N, K, e);
-    STN_HIP(hipMemcpyAsync(out, dO, (size_t)M * N * 4, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-void Engine::op_dwconv_ln(int dtype, int B, int L, int C, int k, int dil, const float* x, const float* w, const float* bias,
-                          const float* g, const float* b, float* y, const int* seqlen) {
-    STN_HIP(hipSetDevice(device_));
-    ar_.reset();
-    const size_t n = (size_t)B * L * C;
-    const int* dlen = seqlen ? up(ar_, s_, seqlen, (size_t)B) : nullptr;
-    std::vector<float> wt((size_t)C * k);
-    for (int c = 0; c < C; ++c) for (int j = 0; j < k; ++j) wt[(size_t)j * C + c] = w[(size_t)c * k + j];
-    float* dx = up(ar_, s_, x, n);
-    float* dw = up(ar_, s_, wt.data(), wt.size());
-    float* db = up(ar_, s_, bias, (size_t)C);
-    float* dg = up(ar_, s_, g, (size_t)C);
-    float* dbt = up(ar_, s_, b, (size_t)C);
-    void* dy = ar_.alloc(n * 4);
-    float* dy32 = f32_alloc(n);
-    launch_dwconv_ln(s_, dtype, dx, B, L, C, dw, db, k, dil, dg, dbt, 1e-6f, dy, dlen);
-    if (is_half(dtype)) launch_half_to_f32(s_, dtype, dy, (int64_t)n, dy32);
-    STN_HIP(hipMemcpyAsync(y, is_half(dtype) ? dy32 : static_cast<float*>(dy), n * 4, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-void Engine::op_attention(int dtype, int B, int Lq, int Lk, int H, int dh, const float* q, const float* k, const float* v,
-                          const int* qlen, const int* klen, int rope_mode, float* o) {
-    STN_HIP(hipSetDevice(device_));
-    ar_.reset();
-    const int C = H * dh;
-    const size_t nq = (size_t)B * Lq * C, nk = (size_t)B * Lk * C;
-    float* dq = up(ar_, s_, q, nq);
-    float* dk = up(ar_, s_, k, nk);
-    float* dv = up(ar_, s_, v, nk);
-    int* dql = qlen ? up(ar_, s_, qlen, (size_t)B) : nullptr;
-    int* dkl = klen ? up(ar_, s_, klen, (size_t)B) : nullptr;
-    const void *pq = dq, *pk = dk, *pv = dv;
-    if (is_half(dtype)) {
-        void* a = ar_.alloc(nq * 2); void* b = ar_.alloc(nk * 2); void* c = ar_.alloc(nk * 2);
-        launch_cast(s_, dtype, dq, (int64_t)nq, a); launch_cast(s_, dtype, dk, (int64_t)nk, b); launch_cast(s_, dtype, dv, (int64_t)nk, c);
-        pq = a; pk = b; pv = c;
-    }
-    void* dO = ar_.alloc(nq * 4);
-    float* dO32 = f32_alloc(nq);
-    const float rbase = a_.rope_base > 0 ? a_.rope_base : 10000.f, rgam = a_.larope_gamma > 0 ? a_.larope_gamma : 10.f;
-    const bool prerot = rope_mode >= 0 && (rope_mode & 0x100) != 0;  // test hook: rotate the keys in a separate pass first
-    if (prerot) rope_mode &= 0xFF;
-    if (prerot) launch_rope_rows(s_, dtype, const_cast<void*>(pk), C, B, Lk, dkl, 1, 0, H, dh, rope_mode, rbase, rgam);
-    launch_attention(s_, dtype, pq, C, pk, pv, C, dO, C, B, Lq, Lk, H, dh, dql, dkl, rope_mode, rbase, rgam, prerot);
-    if (is_half(dtype)) launch_half_to_f32(s_, dtype, dO, (int64_t)nq, dO32);
-    STN_HIP(hipMemcpyAsync(o, is_half(dtype) ? dO32 : static_cast<float*>(dO), nq * 4, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-double Engine::op_gemm_bench(int dtype, int M, int N, int K, int mode, int iters) {
-    STN_HIP(hipSetDevice(device_));
-    ar_.reset();
-    const size_t esz = is_half(dtype) ? 2 : 4;
-    float* tmp = f32_alloc((size_t)std::max((size_t)M * K, (size_t)N * K));
-    void* A = ar_.alloc((size_t)M * K * esz);
-    void* Wt = ar_.alloc((size_t)N * K * esz);
-    launch_randn_masked(s_, 11, nullptr, 1, 1, (int)std::min<size_t>((size_t)M * K, 1u << 30), nullptr, tmp);
-    launch_cast(s_, dtype, tmp, (int64_t)M * K, A);
-    launch_randn_masked(s_, 12, nullptr, 1, 1, (int)std::min<size_t>((size_t)N * K, 1u << 30), nullptr, tmp);
-    launch_scale(s_, tmp, (int)std::min<size_t>((size_t)N * K, 1u << 30), 1.0f / std::sqrt((float)K));
-    launch_cast(s_, dtype, tmp, (int64_t)N * K, Wt);
-    float* bias = f32_alloc(N);
-    float* gamma = f32_alloc(N);
-    launch_fill(s_, bias, N, 0.01f);
-    launch_fill(s_, gamma, N, 0.2f);
-    float* resid = f32_alloc((size_t)M * N);
-    void* out = ar_.alloc((size_t)M * N * 4);
-    STN_HIP(hipMemsetAsync(resid, 0, (size_t)M * N * 4, s_));
-    Epilogue e;
-    e.bias = bias;
-    if (mode == 1) { e.mode = EPI_RESID; e.resid = resid; e.ldo = N; e.gamma = gamma; }
-    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : ACT_GELU; e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
-    for (int i = 0; i < 3; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
-    hipEvent_t a, b;
-    STN_HIP(hipEventCreate(&a));
-    STN_HIP(hipEventCreate(&b));
-    STN_HIP(hipEventRecord(a, s_));
-    for (int i = 0; i < iters; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
-    STN_HIP(hipEventRecord(b, s_));
-    STN_HIP(hipEventSynchronize(b));
-    float ms = 0.f;
-    STN_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    return (double)ms / iters;
-}
-
-void Engine::op_gemm_phases(int dtype, int M, int N, int K, int mode, double* out6) {
-    STN_HIP(hipSetDevice(device_));
-    ar_.reset();
-    const size_t esz = is_half(dtype) ? 2 : 4;
-    float* tmp = f32_alloc((size_t)std::max((size_t)M * K, (size_t)N * K));
-    void* A = ar_.alloc((size_t)M * K * esz);
-    void* Wt = ar_.alloc((size_t)N * K * esz);
-    launch_randn_masked(s_, 11, nullptr, 1, 1, (int)std::min<size_t>((size_t)M * K, 1u << 30), nullptr, tmp);
-    launch_cast(s_, dtype, tmp, (int64_t)M * K, A);
-    launch_randn_masked(s_, 12, nullptr, 1, 1, (int)std::min<size_t>((size_t)N * K, 1u << 30), nullptr, tmp);
-    launch_scale(s_, tmp, (int)std::min<size_t>((size_t)N * K, 1u << 30), 1.0f / std::sqrt((float)K));
-    launch_cast(s_, dtype, tmp, (int64_t)N * K, Wt);
-    float* bias = f32_alloc(N);
-    float* gamma = f32_alloc(N);
-    launch_fill(s_, bias, N, 0.01f);
-    launch_fill(s_, gamma, N, 0.2f);
-    float* resid = f32_alloc((size_t)M * N);
-    void* out = ar_.alloc((size_t)M * N * 4);
-    STN_HIP(hipMemsetAsync(resid, 0, (size_t)M * N * 4, s_));
-    const size_t max_wg = 1 << 16;
-    unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(max_wg * 4 * 8));
-    Epilogue e;
-    e.bias = bias;
-    if (mode == 1) { e.mode = EPI_RESID; e.resid = resid; e.ldo = N; e.gamma = gamma; }
-    else { e.mode = EPI_STORE; e.act = mode == 2 ? ACT_NONE : ACT_GELU; e.out_dtype = mode == 3 ? F32 : dtype; e.out = out; e.ldo = N; }
-    for (int i = 0; i < 3; ++i) launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
-    STN_HIP(hipMemsetAsync(ts, 0, max_wg * 4 * 8, s_));
-    e.ts = ts;
-    launch_gemm(s_, dtype, A, K, Wt, K, M, N, K, e);
-    std::vector<unsigned long long> h(max_wg * 4);
-    STN_HIP(hipMemcpyAsync(h.data(), ts, max_wg * 4 * 8, hipMemcpyDeviceToHost, s_));
-    sync();
-    double p0 = 0, p1 = 0, p2 = 0;
-    unsigned long long tmin = ~0ull, tmax_in = 0, tend = 0;
-    size_t n = 0;
-    for (size_t w = 0; w < max_wg; ++w) {
-        const unsigned long long* t = &h[w * 4];
-        if (t[3] == 0) continue;
-        ++n;
-        p0 += (double)(t[1] - t[0]); p1 += (double)(t[2] - t[1]); p2 += (double)(t[3] - t[2]);
-        tmin = std::min(tmin, t[0]); tmax_in = std::max(tmax_in, t[0]); tend = std::max(tend, t[3]);
-    }
-    if (n == 0) throw std::runtime_error("op_gemm_phases: this shape does not run on the tiled kernel");
-    out6[0] = p0 / n; out6[1] = p1 / n; out6[2] = p2 / n;
-    out6[3] = (double)(tend - tmin); out6[4] = (double)(tmax_in - tmin); out6[5] = (double)n;
-}
-
-void Engine::op_ffn(int M, int C, int I, const float* xn, const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma,
-                    const float* rowvec, const int* row_b, int nseq, float* x, int mode) {
-    STN_HIP(hipSetDevice(device_));
-    const bool fused = mode != 0;
-    if (!is_half(dt_)) throw std::invalid_argument("op_ffn: 16-bit engines only");
-    if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn: shape not supported by the fused kernel");
-    if (mode == 2 && ffn_split_factor(dt_, C, I) < 2) throw std::invalid_argument("op_ffn: shape not supported by the hidden-split kernel");
-    ar_.reset();
-    float* d_xn = up(ar_, s_, xn, (size_t)M * C);
-    float* d_w1 = up(ar_, s_, W1, (size_t)I * C);
-    float* d_w2 = up(ar_, s_, W2, (size_t)C * I);
-    float* d_b1 = up(ar_, s_, b1, (size_t)I);
-    float* d_b2 = b2 ? up(ar_, s_, b2, (size_t)C) : nullptr;
-    float* d_g = gamma ? up(ar_, s_, gamma, (size_t)C) : nullptr;
-    float* d_x = up(ar_, s_, x, (size_t)M * C);
-    float* d_rv = rowvec ? up(ar_, s_, rowvec, (size_t)nseq * C) : nullptr;
-    int* d_rb = (rowvec && row_b) ? up(ar_, s_, row_b, (size_t)M) : nullptr;
-    void* xn16 = act_alloc((int64_t)M * C);
-    void* w1_16 = act_alloc((int64_t)I * C);
-    void* w2_16 = act_alloc((int64_t)I * C);
-    launch_cast(s_, dt_, d_xn, (int64_t)M * C, xn16);
-    launch_cast(s_, dt_, d_w1, (int64_t)I * C, w1_16);
-    launch_cast(s_, dt_, d_w2, (int64_t)I * C, w2_16);
-    if (fused) {
-        void* tmp = act_alloc((int64_t)2 * I * C);
-        void* wseq = act_alloc((int64_t)2 * I * C);
-        const int S = mode == 2 ? ffn_split_choose(dt_, C, I, M) : 1;
-        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
-        FfnArgs fa;
-        fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
-        fa.M = M; fa.I = I; fa.rowvec = d_rv; fa.rv_ld = C; fa.row_b = d_rb; fa.L = M;
-        if (mode == 2) {
-            fa.split = S; fa.part_stride = ffn_split_rows(M) * C; fa.part = act_alloc(fa.part_stride * S);
-            launch_ffn_fused(s_, dt_, C, fa);
-            // the pending update, folded by the LayerNorm form of the fold (its normalised output is not part of this op)
-            float* ones = f32_alloc(C);
-            launch_fill(s_, ones, C, 1.f);
-            float* zeros = f32_alloc(C);
-            launch_fill(s_, zeros, C, 0.f);
-            FoldArgs fo; fo.part = fa.part; fo.S = S; fo.part_stride = fa.part_stride; fo.b2 = d_b2 ? d_b2 : zeros; fo.gamma = d_g ? d_g : ones;
-            fo.rowvec = d_rv; fo.rv_ld = C; fo.row_b = d_rb;
-            void* y = act_alloc((int64_t)M * C);
-            launch_fold_ln(s_, dt_, d_x, M, C, fo, ones, ones, a_.ln_eps, y);
-        } else {
-            launch_ffn_fused(s_, dt_, C, fa);
-        }
-    } else {
-        void* u = act_alloc((int64_t)M * I);
-        Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
-        launch_gemm(s_, dt_, xn16, C, w1_16, C, M, I, C, e1);
-        Epilogue e2; e2.mode = EPI_RESID; e2.resid = d_x; e2.ldo = C; e2.gamma = d_g; e2.bias = d_b2; e2.rowvec = d_rv; e2.rv_ld = C; e2.row_b = d_rb; e2.L = M;
-        launch_gemm(s_, dt_, u, I, w2_16, I, M, C, I, e2);
-    }
-    STN_HIP(hipGetLastError());
-    STN_HIP(hipMemcpyAsync(x, d_x, sizeof(float) * (size_t)M * C, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-void Engine::op_ffn_bench(int M, int C, int I, int mode, int iters, double* out5) {
-    STN_HIP(hipSetDevice(device_));
-    const bool fused = mode != 0;
-    const int S = mode == 2 ? ffn_split_choose(dt_, C, I, M) : 1;
-    if (mode == 2 && S < 2) throw std::invalid_argument("op_ffn_bench: shape not supported by the hidden-split kernel");
-    if (!is_half(dt_)) throw std::invalid_argument("op_ffn_bench: 16-bit engines only");
-    if (fused && !ffn_fused_supported(dt_, C, I)) throw std::invalid_argument("op_ffn_bench: shape not supported by the fused kernel");
-    ar_.reset();
-    for (int i = 0; i < 5; ++i) out5[i] = 0.0;
-    // random operands (the clock a chip holds on zeros is not the clock it holds on data)
-    float* rnd = f32_alloc((int64_t)M * C);
-    launch_randn_masked(s_, 11, nullptr, 1, M, C, nullptr, rnd);
-    float* wr = f32_alloc((int64_t)I * C);
-    launch_randn_masked(s_, 12, nullptr, 1, I, C, nullptr, wr);
-    launch_scale(s_, wr, I * C, 0.05f);
-    void* xn16 = act_alloc((int64_t)M * C);
-    void* w1_16 = act_alloc((int64_t)I * C);
-    void* w2_16 = act_alloc((int64_t)I * C);
-    launch_cast(s_, dt_, rnd, (int64_t)M * C, xn16);
-    launch_cast(s_, dt_, wr, (int64_t)I * C, w1_16);
-    launch_cast(s_, dt_, wr, (int64_t)I * C, w2_16);
-    float* d_b1 = f32_alloc(I);
-    float* d_b2 = f32_alloc(C);
-    float* d_g = f32_alloc(C);
-    launch_fill(s_, d_b1, I, 0.01f); launch_fill(s_, d_b2, C, 0.01f); launch_fill(s_, d_g, C, 0.1f);
-    float* d_x = f32_alloc((int64_t)M * C);
-    STN_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)M * C, s_));
-    void* wseq = nullptr;
-    if (fused) {
-        void* tmp = act_alloc((int64_t)2 * I * C);
-        wseq = act_alloc((int64_t)2 * I * C);
-        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
-    }
-    void* u = fused ? nullptr : act_alloc((int64_t)M * I);
-    const int64_t pstride = ffn_split_rows(M) * C;
-    void* part = mode == 2 ? act_alloc(pstride * S) : nullptr;
-    const int nslab = (M + 127) / 128;
-    const int nwg = mode == 2 ? (nslab + 7) / 8 * 8 * S : nslab;
-    unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
-    auto run = [&](unsigned long long* stamps) {
-        if (fused) {
-            FfnArgs fa;
-            fa.xn = xn16; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.b2 = d_b2; fa.gamma = d_g; fa.x = d_x; fa.ldo = C;
-            fa.M = M; fa.I = I; fa.L = M; fa.ts = stamps;
-            if (mode == 2) { fa.split = S; fa.part = part; fa.part_stride = pstride; }
-            launch_ffn_fused(s_, dt_, C, fa);
-        } else {
-            Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
-            if (nt_hints_ && (double)M * I * 2.0 > 128e6) e1.nt = 1;
-            launch_gemm(s_, dt_, xn16, C, w1_16, C, M, I, C, e1);
-            Epilogue e2; e2.mode = EPI_RESID; e2.resid = d_x; e2.ldo = C; e2.gamma = d_g; e2.bias = d_b2; e2.L = M;
-            launch_gemm(s_, dt_, u, I, w2_16, I, M, C, I, e2);
-        }
-    };
-    for (int i = 0; i < 3; ++i) run(nullptr);
-    hipEvent_t a, b;
-    STN_HIP(hipEventCreate(&a)); STN_HIP(hipEventCreate(&b));
-    STN_HIP(hipEventRecord(a, s_));
-    for (int i = 0; i < iters; ++i) run(nullptr);
-    STN_HIP(hipEventRecord(b, s_));
-    STN_HIP(hipEventSynchronize(b));
-    float ms = 0.f;
-    STN_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    out5[0] = ms / iters;
-    if (fused) {
-        STN_HIP(hipMemsetAsync(ts, 0, sizeof(unsigned long long) * 4 * (size_t)nwg, s_));
-        run(ts);
-        std::vector<unsigned long long> h((size_t)4 * nwg);
-        STN_HIP(hipMemcpyAsync(h.data(), ts, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s_));
-        sync();
-        double s1 = 0, s2 = 0, s3 = 0;
-        int live = 0;  // (workgroups of a hidden-split grid beyond the last slab exit at once and leave no stamps)
-        for (int w = 0; w < nwg; ++w) {
-            if (!h[4 * w + 3]) continue;
-            ++live;
-            s1 += (double)(h[4 * w + 1] - h[4 * w]); s2 += (double)(h[4 * w + 2] - h[4 * w + 1]); s3 += (double)(h[4 * w + 3] - h[4 * w + 2]);
-        }
-        if (live) { out5[1] = s1 / live; out5[2] = s2 / live; out5[3] = s3 / live; }
-        out5[4] = live;
-    }
-    STN_HIP(hipGetLastError());
-    sync();
-}
-
-void Engine::op_fold_dwconv_ln(int B, int C, int k, int dil, int S, const int* seqlen, const float* x, const float* part, const float* b2,
-                               const float* gamma, const float* rowvec, const float* w, const float* bias, const float* g, const float* b,
-                               float* x_out, float* y) {
-    STN_HIP(hipSetDevice(device_));
-    if (!is_half(dt_)) throw std::invalid_argument("op_fold_dwconv_ln: 16-bit engines only");
-    ar_.reset();
-    std::vector<int> off(B + 1, 0);
-    int L = 0;
-    for (int i = 0; i < B; ++i) { off[i + 1] = off[i] + seqlen[i]; L = std::max(L, seqlen[i]); }
-    const int64_t M = off[B];
-    const size_t n = (size_t)M * C;
-    std::vector<float> wt((size_t)C * k);
-    for (int c = 0; c < C; ++c) for (int j = 0; j < k; ++j) wt[(size_t)j * C + c] = w[(size_t)c * k + j];
-    const int* dlen = up(ar_, s_, seqlen, (size_t)B);
-    const int* doff = up(ar_, s_, off.data(), (size_t)B + 1);
-    float* dx = up(ar_, s_, x, n);
-    float* dp32 = up(ar_, s_, part, n * S);
-    float* db2 = b2 ? up(ar_, s_, b2, (size_t)C) : nullptr;
-    float* dgm = gamma ? up(ar_, s_, gamma, (size_t)C) : nullptr;
-    float* drv = rowvec ? up(ar_, s_, rowvec, (size_t)B * C) : nullptr;
-    float* dw = up(ar_, s_, wt.data(), wt.size());
-    float* db = up(ar_, s_, bias, (size_t)C);
-    float* dg = up(ar_, s_, g, (size_t)C);
-    float* dbt = up(ar_, s_, b, (size_t)C);
-    void* dp16 = act_alloc((int64_t)n * S);
-    launch_cast(s_, dt_, dp32, (int64_t)n * S, dp16);
-    float* dxo = f32_alloc((int64_t)n);
-    void* dy = act_alloc((int64_t)n);
-    float* dy32 = f32_alloc((int64_t)n);
-    float* ones = f32_alloc(C);
-    launch_fill(s_, ones, C, 1.f);
-    float* zeros = f32_alloc(C);
-    launch_fill(s_, zeros, C, 0.f);
-    FoldArgs fo; fo.part = dp16; fo.S = S; fo.part_stride = (int64_t)n; fo.b2 = db2 ? db2 : zeros; fo.gamma = dgm ? dgm : ones; fo.rowvec = drv; fo.rv_ld = C;
-    launch_fold_dwconv_ln(s_, dt_, dx, dxo, B, L, C, fo, dw, db, k, dil, dg, dbt, 1e-6f, dy, dlen, doff);
-    launch_half_to_f32(s_, dt_, dy, (int64_t)n, dy32);
-    STN_HIP(hipGetLastError());
-    STN_HIP(hipMemcpyAsync(x_out, dxo, n * 4, hipMemcpyDeviceToHost, s_));
-    STN_HIP(hipMemcpyAsync(y, dy32, n * 4, hipMemcpyDeviceToHost, s_));
-    sync();
-}
-
-void Engine::op_block_bench(int B, int L, int C, int I, int k, int dil, int mode, int iters, double* out2) {
-    STN_HIP(hipSetDevice(device_));
-    if (!is_half(dt_)) throw std::invalid_argument("op_block_bench: 16-bit engines only");
-    const int S = ffn_split_choose(dt_, C, I, (int64_t)B * L);
-    if (mode == 2 && S < 2) throw std::invalid_argument("op_block_bench: shape not supported by the hidden-split kernel");
-    ar_.reset();
-    for (int i = 0; i < 6; ++i) out2[i] = 0.0;
-    const int64_t M = (int64_t)B * L;
-    std::vector<int> len(B, L), off(B + 1);
-    for (int i = 0; i <= B; ++i) off[i] = i * L;
-    const int* dlen = up(ar_, s_, len.data(), (size_t)B);
-    const int* doff = up(ar_, s_, off.data(), (size_t)B + 1);
-    float* xa = f32_alloc(M * C);
-    float* xb = f32_alloc(M * C);
-    launch_randn_masked(s_, 11, nullptr, 1, (int)M, C, nullptr, xa);
-    float* wr = f32_alloc((int64_t)I * C);
-    launch_randn_masked(s_, 12, nullptr, 1, I, C, nullptr, wr);
-    launch_scale(s_, wr, I * C, 0.05f);
-    void* w1_16 = act_alloc((int64_t)I * C);
-    void* w2_16 = act_alloc((int64_t)I * C);
-    launch_cast(s_, dt_, wr, (int64_t)I * C, w1_16);
-    launch_cast(s_, dt_, wr, (int64_t)I * C, w2_16);
-    float* d_b1 = f32_alloc(I);
-    float* d_b2 = f32_alloc(C);
-    float* d_g = f32_alloc(C);
-    float* d_one = f32_alloc(C);
-    float* dwt = f32_alloc((int64_t)k * C);
-    launch_fill(s_, d_b1, I, 0.01f); launch_fill(s_, d_b2, C, 0.01f); launch_fill(s_, d_g, C, 0.01f); launch_fill(s_, d_one, C, 1.f);
-    launch_fill(s_, dwt, k * C, 1.f / k);
-    void* xn = act_alloc(M * C);
-    void* u = mode == 2 ? nullptr : act_alloc(M * I);
-    void* wseq = nullptr;
-    const int64_t pstride = ffn_split_rows(M) * C;
-    void* part = nullptr;
-    if (mode == 2) {
-        void* tmp = act_alloc((int64_t)2 * I * C);
-        wseq = act_alloc((int64_t)2 * I * C);
-        launch_ffn_pack(s_, w1_16, w2_16, C, I, tmp, wseq, S);
-        part = act_alloc(pstride * S);
-        STN_HIP(hipMemsetAsync(part, 0, (size_t)pstride * S * 2, s_));
-    }
-    FoldArgs fo; fo.part = part; fo.S = S; fo.part_stride = pstride; fo.b2 = d_b2; fo.gamma = d_g;
-    auto conv = [&]() {
-        if (mode == 2) { launch_fold_dwconv_ln(s_, dt_, xa, xb, B, L, C, fo, dwt, d_b2, k, dil, d_one, d_b2, 1e-6f, xn, dlen, doff); std::swap(xa, xb); }
-        else launch_dwconv_ln(s_, dt_, xa, B, L, C, dwt, d_b2, k, dil, d_one, d_b2, 1e-6f, xn, dlen, doff);
-    };
-    auto block = [&]() {
-        conv();
-        if (mode == 2) {
-            FfnArgs fa; fa.xn = xn; fa.ldx = C; fa.wseq = wseq; fa.b1 = d_b1; fa.M = (int)M; fa.I = I; fa.split = S; fa.part = part; fa.part_stride = pstride;
-            launch_ffn_fused(s_, dt_, C, fa);
-        } else {
-            Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = I; e1.bias = d_b1;
-            launch_gemm(s_, dt_, xn, C, w1_16, C, (int)M, I, C, e1);
-            Epilogue e2; e2.mode = EPI_RESID; e2.resid = xa; e2.ldo = C; e2.gamma = d_g; e2.bias = d_b2; e2.L = (int)M;
-            launch_gemm(s_, dt_, u, I, w2_16, I, (int)M, C, I, e2);
-        }
-    };
-    hipEvent_t a, b;
-    STN_HIP(hipEventCreate(&a)); STN_HIP(hipEventCreate(&b));
-    for (int which = 0; which < 2; ++which) {
-        for (int i = 0; i < 3; ++i) { if (which) conv(); else block(); }
-        STN_HIP(hipEventRecord(a, s_));
-        for (int i = 0; i < iters; ++i) { if (which) conv(); else block(); }
-        STN_HIP(hipEventRecord(b, s_));
-        STN_HIP(hipEventSynchronize(b));
-        float ms = 0.f;
-        STN_HIP(hipEventElapsedTime(&ms, a, b));
-        out2[which] = ms / iters;
-    }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    if (mode == 2) {  // phase stamps of one fold_dwconv_ln launch
-        const int nwg = B * ((L + 7) / 8);  // (runs of 8 frames when there are few sequences, of 32 otherwise: sized for the shorter)
-        unsigned long long* ts = static_cast<unsigned long long*>(ar_.alloc(sizeof(unsigned long long) * 4 * (size_t)nwg));
-        STN_HIP(hipMemsetAsync(ts, 0, sizeof(unsigned long long) * 4 * (size_t)nwg, s_));
-        fo.ts = ts;
-        conv();
-        fo.ts = nullptr;
-        std::vector<unsigned long long> h((size_t)4 * nwg);
-        STN_HIP(hipMemcpyAsync(h.data(), ts, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s_));
-        sync();
-        double p1 = 0, p2 = 0, p3 = 0; int live = 0;
-        unsigned long long tmin = ~0ull, tmax = 0;
-        for (int w = 0; w < nwg; ++w) {
-            if (!h[4 * w + 3]) continue;
-            ++live;
-            p1 += (double)(h[4 * w + 1] - h[4 * w]); p2 += (double)(h[4 * w + 2] - h[4 * w + 1]); p3 += (double)(h[4 * w + 3] - h[4 * w + 2]);
-            tmin = std::min(tmin, h[4 * w]); tmax = std::max(tmax, h[4 * w + 3]);
-        }
-        if (live) { out2[2] = p1 / live; out2[3] = p2 / live; out2[4] = p3 / live; out2[5] = (double)(tmax - tmin); }
-    }
-    STN_HIP(hipGetLastError());
-    sync();
-}
-
-void Engine::op_randn(uint64_t seed, int B, int D, int L, const int64_t* utt_ids, const int* len, float* out) {
-    STN_HIP(hipSetDevice(device_));
-    ar_.reset();
-    int64_t* du = utt_ids ? up(ar_, s_, utt_ids, (size_t)B) : nullptr;
-    int* dl = len ? up(ar_, s_, len, (size_t)B) : nullptr;
-    float* d = f32_alloc((size_t)B * D * L);
-    launch_randn_masked(s_, seed, du, B, D, L, dl, d);
-    STN_HIP(hipMemcpyAsync(out, d, (size_t)B * D * L * 4, hipMemcpyDeviceToHost, s_));
     sync();
 }
 

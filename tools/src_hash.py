@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def source_sha(root=ROOT):
     h = hashlib.sha256()
     files = []
-    for pat in ("supertonic_amd/csrc/*.hip", "supertonic_amd/csrc/*.inc", "supertonic_amd/csrc/*.hpp", "supertonic_amd/csrc/engine.cpp", "Makefile"):
+    for pat in ("supertonic_amd/csrc/*.hip", "supertonic_amd/csrc/*.inc", "supertonic_amd/csrc/*.hpp", "supertonic_amd/csrc/engine*.cpp", "Makefile"):
         files += glob.glob(os.path.join(root, pat))
     for f in sorted(files):
         h.update(os.path.relpath(f, root).encode())
