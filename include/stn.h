@@ -207,6 +207,13 @@ int stn_profile_count(stn_handle* h);
 int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,
                     double* flops, double* bytes);
 
+/* diagnostics (tools/xattn_hs_phases.py): with on != 0 every head-split cross-attention launch (stn_set_fused_xattn(h, 3), eager runs
+   only) writes 8 shader-clock stamps per workgroup — entry, Wq in LDS, q projection done, K/V in LDS, attention done, Wo in LDS, end,
+   and the workgroup's row-tile count — into one buffer; stn_dbg_xattn_hs_stamps copies the LAST launch's stamps (up to cap values)
+   and returns how many workgroups that launch had. */
+int stn_dbg_xattn_hs_enable(stn_handle* h, int on);
+int64_t stn_dbg_xattn_hs_stamps(stn_handle* h, unsigned long long* out, size_t cap);
+
 /* ---- op-level entry points used by the kernel parity tests (host pointers) -------------------------- */
 int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A /*[M,K]*/, const float* W /*[N,K]*/,
                 const float* bias_or_null, int act /*0 none,1 gelu,2 silu*/, float* out /*[M,N]*/);

@@ -125,6 +125,9 @@ def load():
     L.stn_profile_filter.argtypes = [vp, ctypes.c_char_p]
     L.stn_profile_sample.argtypes = [vp, ci]
     L.stn_launch_log_enable.argtypes = [vp, ci]
+    L.stn_dbg_xattn_hs_enable.argtypes = [vp, ci]
+    L.stn_dbg_xattn_hs_stamps.argtypes = [vp, vp, ctypes.c_size_t]
+    L.stn_dbg_xattn_hs_stamps.restype = ctypes.c_int64
     L.stn_launch_log.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     L.stn_launch_log.restype = ctypes.c_int64
     L.stn_profile_enable.argtypes = [vp, ci]
@@ -379,6 +382,17 @@ class Engine:
         return self.batch_fetch()
 
     # ---- measurement -----------------------------------------------------------------------------------
+    def xattn_hs_stamps_enable(self, on=True):
+        self._ck(self._lib.stn_dbg_xattn_hs_enable(self._h, int(bool(on))))
+
+    def xattn_hs_stamps(self):
+        """[workgroups, 8] shader-clock stamps of the last head-split cross-attention launch (diagnostics)."""
+        n = int(self._lib.stn_dbg_xattn_hs_stamps(self._h, None, 0))
+        out = np.zeros((max(n, 0), 8), np.uint64)
+        if n > 0:
+            self._lib.stn_dbg_xattn_hs_stamps(self._h, out.ctypes.data, out.size)
+        return out
+
     def profile_enable(self, on=True):
         self._ck(self._lib.stn_profile_enable(self._h, int(on)))
 

@@ -335,6 +335,11 @@ int64_t stn_launch_log(stn_handle* h, char* out, size_t cap) {
         return (int64_t)s.size();
     } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_STATE; }
 }
+int stn_dbg_xattn_hs_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->hs_stamps_enable(on != 0); }) }
+int64_t stn_dbg_xattn_hs_stamps(stn_handle* h, unsigned long long* out, size_t cap) {
+    if (!h) return STN_ERR_INVALID;
+    try { return h->eng->hs_stamps_fetch(out, cap); } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_STATE; }
+}
 int stn_profile_sample(stn_handle* h, int every) { STN_TRY(h, { h->eng->profile_sample(every); }) }
 int stn_profile_filter(stn_handle* h, const char* fam) { STN_TRY(h, { h->eng->profile_filter(fam ? fam : ""); }) }
 int stn_profile_reset(stn_handle* h) { STN_TRY(h, { h->eng->profile_reset(); h->prof.clear(); }) }

@@ -126,7 +126,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
-    if (const char* p = getenv("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks in one (1) or two (2) launches
+    if (const char* p = getenv("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks in one (1) or two (2) launches, or head-split (3)
     if (const char* p = getenv("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
@@ -843,7 +843,31 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         const Attn w = attn_w(p, false);
         const char* kp0 = static_cast<const char*>(kv_all) + (size_t)blk * 2 * C * esz;
         const auto fq = frag_w_.find(w.q.w.as(dt_)), fo = frag_w_.find(w.o.w.as(dt_));
-        if (fused_xattn_ && fq != frag_w_.end() && fo != frag_w_.end() && xattn_fused_supported(dt_, C, H, Lk, nb * 2 * C)) {
+        const auto foa = frag_acc_w_.find(w.o.w.as(dt_));
+        if (fused_xattn_ == 3 && fsp && unit_vec_ && C <= 1024 && fq != frag_w_.end() && foa != frag_acc_w_.end() && xattn_hs_supported(dt_, C, H, L, Lk, nb * 2 * C) &&
+            M * C * 2 < 0x7FFFFFFFll) {
+            // HEAD-SPLIT: fold_ln (or LayerNorm), then ONE launch per block — q projection, rotation, attention and the head's share of the
+            // output projection per (utterance pair, head), stored as four 16-bit per-head partial sums in K4-split's layout; the next
+            // ConvNeXt block's fold_dwconv_ln adds them (and the output bias) to x in head order
+            const Arena::Mark m2 = ar_.mark();
+            void* xn = act_alloc(M * C);
+            fold_layernorm(fs, M, C, w.ln, xn, "layernorm");
+            if (kv_all == c.text_kv && text_gate_) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }
+            if (prof_on_) prof_begin("xattn_hs", 4.0 * M * (double)C * C + 4.0 * M * (double)Lk * C,
+                                     (double)M * C * (esz + 2.0 * H) + 2.0 * C * C * esz + (double)B * Lk * 2 * C * esz);
+            unsigned long long* ts = nullptr;
+            if (hs_ts_ && (int64_t)(B + 8) * H <= HS_TS_WG) { ts = hs_ts_; hs_ts_wgs_ = (B + 8) * H; }  // (an upper bound of the grid)
+            launch_xattn_hs(s_, dt_, xn, M, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, foa->second, fs.part, fs.part_stride, B, L, Lk,
+                            llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base, a.larope_gamma, ts);
+            if (prof_on_) prof_end();
+            fs.pending = true;
+            fs.fold = FoldArgs{};
+            fs.fold.part = fs.part; fs.fold.S = H; fs.fold.part_stride = fs.part_stride;
+            fs.fold.b2 = w.o.b ? w.o.b : unit_vec_ + 1024; fs.fold.gamma = unit_vec_;  // x + 1 * (sum + bo): the product with 1 is exact
+            ar_.release(m2);
+            return;
+        }
+        if ((fused_xattn_ == 1 || fused_xattn_ == 2) && fq != frag_w_.end() && fo != frag_w_.end() && xattn_fused_supported(dt_, C, H, Lk, nb * 2 * C)) {
             // fold (when the previous block left one), LayerNorm, q projection, attention, output projection and the residual add in ONE launch
             if (kv_all == c.text_kv && text_gate_) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }
             if (fused_xattn_ == 2) {  // two launches, the q rows through a buffer
@@ -935,10 +959,43 @@ int Engine::vocoder_receptive_field() const {
 // The vocoder's response to zero latent is position-independent away from data and edges.  One run on a short all-zero
 // latent yields the two pieces every padded tail is made of: the frame whose whole receptive field is zero latent ("quiet"),
 // and the last rf frames before the end of the tensor ("edge").  16-bit engines only (the packed vocoder path).
+void Engine::hs_stamps_enable(bool on) {
+    sync();
+    drop_graphs();  // a captured pipeline has the stamp buffer (or its absence) baked in
+    if (on && !hs_ts_) {
+        void* d = nullptr;
+        STN_HIP(hipMalloc(&d, sizeof(unsigned long long) * 8 * HS_TS_WG));
+        STN_HIP(hipMemset(d, 0, sizeof(unsigned long long) * 8 * HS_TS_WG));
+        hs_ts_ = static_cast<unsigned long long*>(d);
+    } else if (!on && hs_ts_) {
+        (void)hipFree(hs_ts_);
+        hs_ts_ = nullptr;
+    }
+    hs_ts_wgs_ = 0;
+}
+int64_t Engine::hs_stamps_fetch(unsigned long long* out, size_t cap) {
+    if (!hs_ts_) return 0;
+    sync();
+    const size_t n = std::min(cap, (size_t)hs_ts_wgs_ * 8);
+    if (out && n) STN_HIP(hipMemcpy(out, hs_ts_, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return hs_ts_wgs_;
+}
+
 void Engine::prepare_xattn_weights() {
     frag_w_.clear();
+    frag_acc_w_.clear();
     const stn_arch& a = a_;
+    unit_vec_ = nullptr;
     if (!is_half(dt_) || !xattn_fused_supported(dt_, a.ve_dim, a.ve_heads, 1, 8)) return;
+    {
+        std::vector<float> uv(2048, 0.f);
+        std::fill(uv.begin(), uv.begin() + 1024, 1.f);
+        void* d = nullptr;
+        STN_HIP(hipMalloc(&d, uv.size() * sizeof(float)));
+        owned_.push_back(d);
+        STN_HIP(hipMemcpy(d, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice));
+        unit_vec_ = static_cast<const float*>(d);
+    }
     for (int blk = 0; blk < a.ve_main_blocks; ++blk)
         for (const char* kind : {".text", ".style"}) {
             const Attn w = attn_w("ve.m" + std::to_string(blk) + kind, false);
@@ -949,6 +1006,14 @@ void Engine::prepare_xattn_weights() {
                 owned_.push_back(dst);
                 launch_repack_frag(s_, src, lin->N, lin->K, dst);
                 frag_w_[src] = dst;
+            }
+            {   // Wo once more in the k order of an accumulator used as the B operand (the head-split block's output projection)
+                const void* src = w.o.w.as(dt_);
+                void* dst = nullptr;
+                STN_HIP(hipMalloc(&dst, (size_t)w.o.N * w.o.K * 2));
+                owned_.push_back(dst);
+                launch_repack_frag_acc(s_, src, w.o.N, w.o.K, dst);
+                frag_acc_w_[src] = dst;
             }
         }
     sync();

@@ -116,6 +116,14 @@ class Engine {
     int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
     void prepare_xattn_weights();         // fragment-ordered copies of the estimator's cross-attention Wq / Wo (kernels_xattn.hip)
     std::unordered_map<const void*, const void*> frag_w_;  // row-major 16-bit matrix -> its fragment-ordered copy
+    // diagnostics: stamps of the head-split cross-attention launches (stn_dbg_xattn_hs_*)
+    void hs_stamps_enable(bool on);
+    int64_t hs_stamps_fetch(unsigned long long* out, size_t cap);
+    unsigned long long* hs_ts_ = nullptr;  // 8 values per workgroup, HS_TS_WG workgroups
+    int hs_ts_wgs_ = 0;                    // workgroups of the last stamped launch
+    static constexpr int HS_TS_WG = 8192;
+    const float* unit_vec_ = nullptr;  // 1024 ones, then 1024 zeros: layer scale / bias of a fold that has none (the head-split block's output: gamma = 1)
+    std::unordered_map<const void*, const void*> frag_acc_w_;  // ... -> its copy in accumulator-operand k order (Wo of the head-split block, kernels_xattn_hs.hip)
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
     void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
     struct FfnW { const void* wseq = nullptr; const void* wsplit[3] = {nullptr, nullptr, nullptr}; };  // wsplit: the hidden-split stage streams for S = 4, 12, 24
@@ -170,7 +178,7 @@ class Engine {
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
     // cross-attention blocks of the estimator as ONE launch each (kernels_xattn.hip) instead of four
-    void set_fused_xattn(int mode) { fused_xattn_ = mode < 0 || mode > 2 ? 0 : mode; }  // 0: four launches, 1: one, 2: two (cut behind the q projection)
+    void set_fused_xattn(int mode) { fused_xattn_ = mode < 0 || mode > 3 ? 0 : mode; }  // 0: four launches, 1: one, 2: two (cut behind the q projection), 3: head-split (fold_ln + one launch, kernels_xattn_hs.hip)
     // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
     // 4 = text encoder / duration predictor.  bf16 engines, widths 256 / 384 / 512 (ffn_fused_supported)
     // 8 = the estimator's blocks as K4-split (hidden dimension cut over 4 workgroups per 128-row slab, 16-bit partial sums folded
@@ -352,7 +360,8 @@ class Engine {
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int64_t ffn_split_min_rows_ = 1;     // K4-split from this many rows on (with the slab staged through LDS one utterance gains too: 20.0 vs 21.4 us per block); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
-    int fused_xattn_ = 0;  // cross-attention blocks of the estimator: 0 four launches, 1 one launch, 2 two launches (kernels_xattn.hip); STN_XATTN=<0|1|2> overrides
+    int fused_xattn_ = 3;  // cross-attention blocks of the estimator: 3 head-split (fold_ln + one launch, kernels_xattn_hs.hip; the default), 0 four launches,
+                           // 1 one launch per utterance tile, 2 the same cut in two (kernels_xattn.hip); STN_XATTN=<0..3> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }

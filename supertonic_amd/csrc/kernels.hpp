@@ -209,6 +209,15 @@ void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, c
                         const int* qlen, const int* klen, const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma,
                         const FoldArgs* fold = nullptr, int part = 0 /* 0: one launch; 1 / 2: the two halves, q rows through qbuf */,
                         void* qbuf = nullptr);
+// The same block HEAD-SPLIT (kernels_xattn_hs.hip): one launch computes, per head h, q_h = Wq_h . xn + bq_h, its rotation, the attention
+// over the given K / V and the head's share of the output projection, and stores it as a 16-bit partial sum part[h][row][:] in K4-split's
+// layout; x <- x + ((p0 + p1) + p2) + p3 + bo is applied by the next reader of x through FoldArgs{part, S = 4, b2 = bo} (launch_fold_dwconv_ln
+// / launch_fold_ln).  xn = LayerNorm(x) rows (16-bit, [M][C]); WqF = launch_repack_frag(Wq), WoA = launch_repack_frag_acc(Wo), both [C][C];
+// packed query rows (q_off, qlen) only; keys already rotated when rope_mode >= 0.  ts: optional 8 shader-clock stamps per workgroup.
+bool xattn_hs_supported(int dtype, int C, int H, int L, int Lk, int ldk);
+void launch_xattn_hs(hipStream_t s, int dtype, const void* xn, int64_t M, const void* WqF, const float* bq, const void* kp, const void* vp, int ldk,
+                     const void* WoA, void* part, int64_t part_stride, int B, int L, int Lk, const int* qlen, const int* klen,
+                     const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma, unsigned long long* ts = nullptr);
 // in-place RoPE of `groups` key blocks per row: element (row b*L+t, column g*group_stride + h*dh + i) for t < len[b]
 // (len null: all rows).  Keys that are reused by many attention launches (the vector estimator's text keys: every
 // block of every Euler step) are rotated once here instead of at every launch.  Same arithmetic as the attention
