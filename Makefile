@@ -9,14 +9,14 @@ CSRC    := supertonic_amd/csrc
 NOPKF32 := -Xclang -target-feature -Xclang -packed-fp32-ops
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude $(NOPKF32) $(EXTRA)
 KERNELS := $(CSRC)/kernels_gemm.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_attn.hip $(CSRC)/kernels_xattn.hip $(CSRC)/kernels_xattn_hs.hip $(CSRC)/kernels_ffn.hip
-HOSTSRC := $(CSRC)/engine.cpp $(CSRC)/engine_batch.cpp $(CSRC)/engine_ops.cpp $(CSRC)/api.cpp $(wildcard $(CSRC)/host/*.cpp)
+HOSTSRC := $(CSRC)/engine.cpp $(CSRC)/engine_batch.cpp $(CSRC)/engine_ops.cpp $(CSRC)/api.cpp $(CSRC)/group.cpp $(wildcard $(CSRC)/host/*.cpp)
 OBJS    := $(patsubst %.hip,build/%.o,$(KERNELS)) $(patsubst %.cpp,build/%.o,$(HOSTSRC))
 HDRS    := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.inc $(CSRC)/host/*.hpp include/*.h)
 
 all: supertonic_amd/libstn.so supertonic_amd/example_native oracle
 
 supertonic_amd/libstn.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 supertonic_amd/example_native: $(CSRC)/cli/example_native.cpp supertonic_amd/libstn.so $(HDRS)
 	$(HIPCC) -O2 -std=c++17 -Iinclude -o $@ $< -Lsupertonic_amd -lstn -Wl,-rpath,'$$ORIGIN'

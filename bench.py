@@ -46,17 +46,37 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process could use, WITHOUT loading a HIP runtime here (the parent of the ranks stays clear of the GPU: a runtime handle
+    held by it for the whole run serves nothing): the *_VISIBLE_DEVICES lists when set, else the KFD topology (nodes with SIMDs are
+    GPUs).  None when neither can be read — the ranks then check for themselves and fail with exit code 2."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here — one process per GPU through
-    torch.distributed.run — BEFORE anything in this process touches a GPU, pass rank 0's JSON line through (the children inherit
-    stdout) and return their exit code.  Fewer than N visible GPUs is an error, never a silent one-rank run."""
+    torch.distributed.run, as a CHILD process — pass rank 0's JSON line through (the children inherit stdout) and return their exit
+    code.  This parent never loads a HIP runtime (visible_gpus()).  Fewer than N visible GPUs is an error, never a silent one-rank run."""
     import socket
     import subprocess
     stub = os.environ.get("STN_BENCH_STUB") == "1"
     if not stub:
-        import torch
-        have = torch.cuda.device_count()  # (counts devices without initialising the runtime)
-        if have < args.gpus:
+        have = visible_gpus()
+        if have is not None and have < args.gpus:
             print(f"[bench] error: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to run a smaller job under that label",
                   file=sys.stderr)
             return 2
@@ -127,12 +147,6 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    import torch
-    import torch.distributed as dist
-    from supertonic_amd import binding, host, workload
-    from supertonic_amd.arch import default_arch
-    from supertonic_amd.dist import GatherPlan, shard_by_length
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -140,17 +154,33 @@ def main():
         if rank == 0:
             print(f"[bench] error: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
         sys.exit(2)
-    if torch.cuda.device_count() <= local:
-        print(f"[bench] error: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible", file=sys.stderr)
-        sys.exit(2)
     # the multi-GPU code path (process group, shared stream, waveform gather); STN_BENCH_FORCE_DIST=1 exercises it at world 1
     use_dist = world > 1 or os.environ.get("STN_BENCH_FORCE_DIST") == "1"
+    # One GPU needs nothing from PyTorch: the run then stays on the HIP runtime libstn.so was built against (the system ROCm) instead of
+    # the copy bundled with the torch wheel, which importing torch first would bind the library to — measure on the runtime you ship.
+    # Only the N > 1 ranks (torch.distributed over RCCL for the gather) import torch, before the library (binding.load()).
+    torch = dist = None
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+    else:
+        os.environ["STN_NO_TORCH_PRELOAD"] = "1"
+    from supertonic_amd import binding, host, workload
+    from supertonic_amd.arch import default_arch
+    if use_dist:
+        from supertonic_amd.dist import GatherPlan
+    n_dev = torch.cuda.device_count() if use_dist else binding.device_count()
+    if n_dev <= local:
+        print(f"[bench] error: rank {rank} wants GPU {local} but only {n_dev} are visible", file=sys.stderr)
+        sys.exit(2)
+    dev = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    rt_info = binding.runtime_info()
 
     # ---- workload: 128*N utterances, sorted by length and dealt round-robin ---------------------
     arch = default_arch()
@@ -208,7 +238,10 @@ def main():
                 gather_buf["plan"].wait(1)
             dist.barrier()
         eng.sync()
-        torch.cuda.synchronize()
+        if use_dist:
+            torch.cuda.synchronize()
+        else:
+            binding.device_sync(local)  # hipDeviceSynchronize through libstn.so: the same device-wide fence, no PyTorch in the process
 
     def timed(k_steps):
         """K steps between barrier + synchronize on both sides; the MAX over ranks."""
@@ -369,7 +402,7 @@ def main():
         B, L, W = eng.batch_dims()
         out = {
             "metric": "audio-sec/sec (RTF^-1), 66M model, batch=128 per GPU" if args.scaling == "weak" else "audio-sec/sec (RTF^-1), 66M model, batch=128 in all (strong scaling)",
-            "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": n_warm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"C4: batch={args.batch} mixed-length (4..48 words) English utterances per GPU, "
@@ -385,6 +418,7 @@ def main():
                        "timed_region": f"{args.steps} syntheses of the resident batch as hipGraph replays of the post-duration pipeline ({replays_timed} replays counted); "
                                        f"{n_warm} untimed warm-up steps (eager, capture, first replay)",
                        "warmup_steps_run": n_warm,
+                       "hip_built": rt_info["hip_built"], "hip_runtime": rt_info["hip_runtime"], "torch_in_process": bool(rt_info["torch_preloaded"]),
                        "parallelism": f"utterance-sharded x{world}, RCCL gather of int16 PCM to rank 0 overlapped with the next step" if world > 1 else "single GPU"},
             "p50_latency_ms": round(p50, 3),
             "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM), graph replay",

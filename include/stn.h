@@ -259,6 +259,10 @@ const char* stn_version(void);
 /* HIP runtime versions: the one libstn.so was compiled against and the one it runs on (they differ when the process loaded
  * PyTorch-ROCm's bundled runtime first); no device needed */
 int stn_hip_versions(int* built, int* runtime);
+/* Visible HIP devices (< 0: STN_ERR_DEVICE), and a device-wide synchronize (hipDeviceSynchronize on `device`): what a host that does not
+ * link a HIP runtime itself needs around a timed region (bench.py --gpus 1 runs without PyTorch, on the runtime this library ships against). */
+int stn_device_count(void);
+int stn_device_sync(int device);
 /* forms of the pointwise pair the kernels offer for a block shape (no device needed): 0 = two tiled launches only, 1 = K4,
  * 2 = K4 and K4-split.  Counts the LDS a workgroup needs (ring + biases <= 160 KiB), so a descriptor that loads never selects a
  * kernel that cannot launch. */

@@ -42,6 +42,21 @@ def runtime_info(L=None):
     return {"hip_built": b.value, "hip_runtime": r.value, "torch_preloaded": "torch" in sys.modules, "lib": LIB_PATH}
 
 
+def device_count():
+    """Visible HIP devices, through libstn.so (no PyTorch needed)."""
+    n = load().stn_device_count()
+    if n < 0:
+        raise StnError(n, "hipGetDeviceCount failed")
+    return n
+
+
+def device_sync(device=0):
+    """hipDeviceSynchronize on `device`, through libstn.so."""
+    rc = load().stn_device_sync(int(device))
+    if rc < 0:
+        raise StnError(rc, "hipDeviceSynchronize failed")
+
+
 def _check_runtime(L):
     """libstn.so's code objects are built and tested with the system ROCm; when the process bound it to another HIP runtime major.minor
     (torch's bundled copy), say so once: not an error — the GPU suite runs in exactly that configuration and
@@ -76,6 +91,8 @@ def load():
     vp, ci, cu64, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
     L.stn_hip_versions.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.stn_ffn_fused_forms.argtypes = [ci, ci, ci]
+    L.stn_device_count.argtypes = []
+    L.stn_device_sync.argtypes = [ci]
     _check_runtime(L)
     L.stn_version.restype = ctypes.c_char_p
     L.stn_create.argtypes = [ctypes.POINTER(StnConfig), ctypes.POINTER(vp)]
@@ -149,8 +166,90 @@ def load():
     L.stn_set_fused_ffn_min_rows.argtypes = [vp, ctypes.c_int64, ctypes.c_int64]
     L.stn_op_fold_dwconv_ln.argtypes = [vp, ci, ci, ci, ci, ci, _i32p, _f32p, _f32p, vp, vp, vp, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     L.stn_op_block_bench.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    # include/stn_group.h: several devices in one process
+    L.stn_group_create.argtypes = [ci, vp, ci, ctypes.POINTER(vp)]
+    L.stn_group_destroy.argtypes = [vp]
+    L.stn_group_last_error.restype = ctypes.c_char_p
+    L.stn_group_last_error.argtypes = [vp]
+    L.stn_group_size.argtypes = [vp]
+    L.stn_group_uses_rccl.argtypes = [vp]
+    L.stn_group_handle.restype = vp
+    L.stn_group_handle.argtypes = [vp, ci]
+    L.stn_group_load_synthetic.argtypes = [vp, ctypes.POINTER(StnArch), cu64]
+    L.stn_group_load_dir.argtypes = [vp, ctypes.c_char_p]
+    L.stn_group_deal.argtypes = [ci, _i32p, ci, _i32p, _i32p]
+    L.stn_group_synthesize.argtypes = [vp, ci, ci, _i64p, _f32p, _f32p, _f32p, ci, cf, vp, cu64, ctypes.POINTER(ctypes.c_int64)]
+    L.stn_group_fetch_pcm16.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.stn_group_last_shards.argtypes = [vp, _i32p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
     _LIB = L
     return L
+
+
+def group_deal(lengths, n_ranks):
+    """include/stn_group.h's deal (host only): (rank_of, row_of) for utterances of these token counts."""
+    lengths = _c(lengths, np.int32)
+    rank_of, row_of = np.empty(len(lengths), np.int32), np.empty(len(lengths), np.int32)
+    rc = load().stn_group_deal(len(lengths), lengths, int(n_ranks), rank_of, row_of)
+    if rc < 0:
+        raise StnError(rc, "stn_group_deal: invalid arguments")
+    return rank_of, row_of
+
+
+class Group:
+    """n devices in one process (include/stn_group.h): one engine per device, utterances dealt by length, 16-bit PCM gathered into the
+    first device (RCCL when the devices are distinct; the same ordinal repeated is a rehearsal on one GPU)."""
+
+    def __init__(self, devices, dtype="bf16"):
+        self._lib = load()
+        self._g = ctypes.c_void_p()
+        devices = list(range(devices)) if isinstance(devices, int) else list(devices)
+        arr = (ctypes.c_int * len(devices))(*devices)
+        rc = self._lib.stn_group_create(len(devices), arr, _DTYPES[dtype], ctypes.byref(self._g))
+        if rc < 0:
+            self._g = None
+            raise StnError(rc, self._lib.stn_group_last_error(None).decode())
+        self.n = len(devices)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.stn_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise StnError(rc, self._lib.stn_group_last_error(self._g).decode())
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.stn_group_uses_rccl(self._g))
+
+    def load_synthetic(self, arch: StnArch, seed: int = 7):
+        self._ck(self._lib.stn_group_load_synthetic(self._g, ctypes.byref(arch), seed))
+
+    def load_dir(self, onnx_dir: str):
+        self._ck(self._lib.stn_group_load_dir(self._g, onnx_dir.encode()))
+
+    def synthesize(self, text_ids, text_mask, style_ttl, style_dp, total_step=5, speed=1.05, duration_override=None, noise_seed=1234):
+        """-> (pcm [B, W] int16 in caller order, duration [B])"""
+        B, Lt = text_ids.shape
+        _d, dptr = _opt(duration_override, np.float32)
+        W = ctypes.c_int64()
+        self._ck(self._lib.stn_group_synthesize(self._g, B, Lt, _c(text_ids, np.int64), _c(text_mask, np.float32), _c(style_ttl, np.float32),
+                                                _c(style_dp, np.float32), total_step, speed, dptr, noise_seed, ctypes.byref(W)))
+        pcm, dur = np.empty((B, W.value), np.int16), np.empty(B, np.float32)
+        self._ck(self._lib.stn_group_fetch_pcm16(self._g, pcm.ctypes.data, pcm.size, dur.ctypes.data))
+        return pcm, dur
+
+    def last_shards(self):
+        rows, samples = np.zeros(self.n, np.int32), np.zeros(self.n, np.int64)
+        self._ck(self._lib.stn_group_last_shards(self._g, rows, samples))
+        return rows, samples
 
 
 def _c(a, dt):

@@ -58,6 +58,15 @@ int stn_hip_versions(int* built, int* runtime) {
     if (runtime) *runtime = e == hipSuccess ? rt : -1;
     return e == hipSuccess ? STN_OK : STN_ERR_DEVICE;
 }
+int stn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return STN_ERR_DEVICE; }
+    return n;
+}
+int stn_device_sync(int device) {
+    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return STN_ERR_DEVICE; }
+    return STN_OK;
+}
 /* which form of the pointwise pair the kernels offer for a block shape: 0 = two tiled launches only, 1 = K4, 2 = K4 and K4-split */
 int stn_ffn_fused_forms(int dtype, int C, int I) {
     if (C <= 0 || I <= 0 || !stn::ffn_fused_supported(dtype, C, I)) return 0;

@@ -1,6 +1,7 @@
 // example_native.cpp — command-line driver with the reference's flags (/root/reference/cpp/example_onnx.cpp:35-50):
 //   --onnx-dir --total-step --speed --n-test --voice-style --text --lang --save-dir --batch
-// plus engine flags: --device N, --dtype {fp32,bf16,fp16}, --seed S (0 = unseeded noise, like the reference).
+// plus engine flags: --device N, --gpus N (deal the batch over N devices: include/stn_group.h), --devices a,b,.. (explicit ordinals),
+// --dtype {fp32,bf16,fp16}, --seed S (0 = unseeded noise, like the reference).
 // Voice styles: paths to voice-style JSON files; when the model assets are absent (synthetic weights) a
 // non-existing path is taken as a voice NAME and mapped to a deterministic synthetic style.
 #include <sys/stat.h>
@@ -52,6 +53,8 @@ int main(int argc, char* argv[]) {
         else if (a == "--save-dir" && more) save_dir = argv[++i];
         else if (a == "--batch") batch = true;
         else if (a == "--device" && more) opts.device = std::atoi(argv[++i]);
+        else if (a == "--gpus" && more) opts.gpus = std::atoi(argv[++i]);  // > 1: the batch is dealt over devices device .. device + N - 1
+        else if (a == "--devices" && more) { for (const std::string& d : split(argv[++i], ',')) opts.devices.push_back(std::atoi(d.c_str())); }
         else if (a == "--dtype" && more) { const std::string d = argv[++i]; opts.dtype = d == "fp32" ? STN_DTYPE_F32 : d == "fp16" ? STN_DTYPE_F16 : STN_DTYPE_BF16; }
         else if (a == "--seed" && more) opts.noise_seed = std::strtoull(argv[++i], nullptr, 10);
         else if (a == "--synthetic") opts.allow_synthetic = true;  // no model assets: run the default architecture on synthetic weights

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../../include/stn.h"
+#include "../../../include/stn_group.h"
 #include "text_frontend.hpp"
 
 namespace stn {
@@ -51,6 +52,9 @@ struct EngineOptions {
                                    // error on unreadable assets (cpp/helper.cpp:805)
     uint64_t weight_seed = 7;
     uint64_t noise_seed = 0;       // 0 -> from std::random_device per call, like the unseeded reference
+    int gpus = 1;                  // > 1: the batch is dealt over this many devices (include/stn_group.h: devices `device`, device + 1, ...;
+                                   // weights replicated, 16-bit PCM gathered into the first over RCCL).  CLI --gpus N
+    std::vector<int> devices;      // explicit ordinals instead (size = gpus); the same ordinal repeated = a rehearsal on one GPU
 };
 
 class TextToSpeech {
@@ -58,6 +62,8 @@ class TextToSpeech {
     struct SynthesisResult { std::vector<float> wav; std::vector<float> duration; };
 
     TextToSpeech(stn_handle* engine, UnicodeProcessor text_processor, const Config& cfgs, uint64_t noise_seed);
+    // several devices: the group owns the handles (engine() is rank 0's); batch() / call() deal their utterances over the group
+    TextToSpeech(stn_group* group, UnicodeProcessor text_processor, const Config& cfgs, uint64_t noise_seed);
     ~TextToSpeech();
     TextToSpeech(const TextToSpeech&) = delete;
 
@@ -69,6 +75,7 @@ class TextToSpeech {
                           const Style& style, int total_step, float speed = 1.05f);
     int getSampleRate() const { return cfgs_.ae.sample_rate; }
     stn_handle* engine() const { return h_; }
+    stn_group* group() const { return grp_; }  // null with one device
     bool synthetic() const { return synthetic_; }
     void markSynthetic() { synthetic_ = true; }
 
@@ -76,6 +83,7 @@ class TextToSpeech {
     SynthesisResult infer(const std::vector<std::string>& text_list, const std::vector<std::string>& lang_list,
                           const Style& style, int total_step, float speed);
     stn_handle* h_;
+    stn_group* grp_ = nullptr;
     UnicodeProcessor text_processor_;
     Config cfgs_;
     uint64_t noise_seed_;

@@ -27,6 +27,10 @@ def test_bench_json_line_contract():
     assert d["graph_replays_in_timed_region"] == d["steps"] and d["config"]["warmup_steps_run"] >= 3
     assert d["eager_sampled"]["ms_per_step"] > 0 and d["eager_sampled"]["ms_per_step"] > 0.9 * d["ms_per_step"]
     assert d["vs_baseline"] is None and d["unit"] == "audio-sec/sec" and d["dtype"] == "bf16" and "synthetic" in d["data"]
+    # one GPU needs no PyTorch: the run stays on the HIP runtime the library was built against, and says so; no version-mismatch warning
+    assert d["config"]["torch_in_process"] is False and d["config"]["hip_runtime"] // 100000 == d["config"]["hip_built"] // 100000, d["config"]
+    assert "was built against HIP" not in p.stderr, p.stderr[-1500:]
+    assert d["warmup_run"] >= 3
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1000 and abs(d["value"] - d["config"]["audio_sec_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     r = d["roofline"]
@@ -83,8 +87,8 @@ def test_bench_multi_gpu_code_path_at_world_1():
 
 
 def test_bench_refuses_more_gpus_than_the_box_has():
-    import torch
-    n = torch.cuda.device_count()
+    from supertonic_amd import binding
+    n = binding.device_count()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "1"], capture_output=True, text=True,
                        timeout=300, cwd=ROOT)
     assert p.returncode != 0 and "visible" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

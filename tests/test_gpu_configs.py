@@ -122,67 +122,50 @@ def test_c4_full_size_sharding_invariance(eng_bf16):
         assert mx < 2e-2, (i, mx)  # different tile shapes / summation orders in bf16, same math
 
 
-def test_c4_full_size_all_eight_shards_on_one_gpu(eng_bf16):
-    """BASELINE.json configs[3] at FULL size: the 1024 mixed-length utterances (4..48 words), length-sorted and dealt round-robin
-    over 8 ranks exactly as bench.py --mixed --gpus 8 deals them; the eight 128-utterance shards run one after another on this GPU
-    and their 16-bit PCM lands in the blocks a gather into rank 0 would fill (GatherPlan.local: the root's receive buffers).  Every
-    utterance arrives, is finite and non-silent over its own samples; utterances re-synthesized in ANOTHER batch composition (three
-    from every shard, mixed into one batch) give the same latent — the independence the sharding relies on
-    (/root/reference/cpp/helper.cpp:477: the batch is only a leading dimension)."""
-    import torch
-    from supertonic_amd.dist import GatherPlan
+def test_c4_full_size_all_eight_ranks_on_one_gpu(eng_bf16):
+    """BASELINE.json configs[3] at FULL size through the native group path (include/stn_group.h): the 1024 mixed-length utterances
+    (4..48 words) dealt over EIGHT ranks — length-sorted, round-robin, as on 8 GPUs — that share this box's one GPU (the rehearsal
+    form: eight engines, eight streams and worker threads, the gather into rank 0 as device copies instead of RCCL sends), fetched in
+    caller order.  Every utterance arrives with its duration, is finite and non-silent over its own samples; 24 utterances
+    re-synthesized in ANOTHER batch composition (three from every rank, mixed into one batch on a single engine) give the same
+    waveform to bf16 rounding — the independence the sharding relies on (/root/reference/cpp/helper.cpp:477: the batch is only a
+    leading dimension)."""
     a = default_arch()
     texts_all = workload.utterances(1024, min_words=4, max_words=48, seed=1234)
-    shards = shard_by_length([len(t) for t in texts_all], 8)
     durs_all = workload.forced_durations(texts_all)
-    # shapes first (what GatherPlan's one-time all-gather exchanges): B and W = L * chunk samples per shard
-    shapes = []
-    for r in range(8):
-        _, L, _ = host.latent_geometry(durs_all[shards[r]] / np.float32(1.05), a.sample_rate, a.base_chunk_size, a.chunk_compress_factor, a.latent_dim)
-        shapes.append((len(shards[r]), L * a.chunk_size))
-    plan = GatherPlan.local(shapes, torch.device("cuda", 0), torch.int16)
-    keep = {}
-    for r in range(8):
-        mine = shards[r]
-        texts = [texts_all[i] for i in mine]
-        tid, mask, sttl, sdp = _prep(texts, ["en"] * len(texts), mine)
-        eng_bf16.batch_upload(tid, mask, sttl, sdp, duration_override=durs_all[mine], utt_ids=mine)
-        eng_bf16.batch_run(5, 1.05, 1234)
-        B, L, W = eng_bf16.batch_dims()
-        assert (B, W) == shapes[r]
-        eng_bf16.batch_copy_pcm16_device(plan.wav_ptr(r), plan.stride)
-        _, dur = eng_bf16.batch_fetch(want_wav=False)
-        plan.set_durations(torch.from_numpy(dur).cuda(), r)
-        lat = eng_bf16.batch_fetch_latent()
-        assert np.all(np.isfinite(lat))
-        for j in (3, 64, 125):
-            keep[int(mine[j])] = lat[j].copy()
-    torch.cuda.synchronize()
-    wavs, durs_g = plan.result(0)
-    assert len(wavs) == 8 and sum(w.shape[0] for w in wavs) == 1024
-    seen = 0
-    for r in range(8):
-        pcm, d = wavs[r].cpu().numpy(), durs_g[r].cpu().numpy()
-        assert pcm.shape == shapes[r] and pcm.dtype == np.int16
-        np.testing.assert_allclose(d, durs_all[shards[r]] / np.float32(1.05), rtol=1e-6)
-        ns = np.floor(d * a.sample_rate).astype(int)
-        for j in range(pcm.shape[0]):
-            own = pcm[j, :ns[j]]
-            assert own.size > 1000 and np.abs(own.astype(np.int32)).max() > 0  # arrived and is not silence
-            seen += 1
-    assert seen == 1024
-    # another composition: the 24 kept utterances as ONE batch (different lengths, different neighbours, different kernel regimes)
-    ids2 = np.array(sorted(keep), dtype=np.int64)
+    tid, mask, sttl, sdp = _prep(texts_all, ["en"] * 1024, np.arange(1024))
+    g = binding.Group([0] * 8, "bf16")
+    g.load_synthetic(a, 7)
+    pcm, dur = g.synthesize(tid, mask, sttl, sdp, 5, 1.05, duration_override=durs_all, noise_seed=1234)
+    rows, samples = g.last_shards()
+    g.close()
+    assert list(rows) == [128] * 8 and pcm.shape == (1024, samples.max()) and pcm.dtype == np.int16
+    np.testing.assert_allclose(dur, durs_all / np.float32(1.05), rtol=1e-6)
+    rank_of, row_of = binding.group_deal(mask.sum(axis=(1, 2)).astype(np.int32), 8)
+    ns = np.floor(dur * a.sample_rate).astype(int)
+    for i in range(1024):
+        own = pcm[i, :ns[i]]
+        assert own.size > 1000 and np.abs(own.astype(np.int32)).max() > 0, i  # arrived and is not silence
+        assert np.all(pcm[i, samples[rank_of[i]]:] == 0)                        # behind its shard's own row length: zeros
+    # another composition: three utterances of every rank as ONE batch on a single engine (different lengths, neighbours, kernel regimes)
+    ids2 = np.array(sorted(int(np.where((rank_of == r) & (row_of == j))[0][0]) for r in range(8) for j in (3, 64, 125)), dtype=np.int64)
     t2 = [texts_all[i] for i in ids2]
     tid2, mask2, sttl2, sdp2 = _prep(t2, ["en"] * len(t2), ids2)
-    eng_bf16.synthesize(tid2, mask2, sttl2, sdp2, 5, 1.05, duration_override=durs_all[ids2], noise_seed=1234, utt_ids=ids2)
-    lat2 = eng_bf16.batch_fetch_latent()
-    _, _, lens2 = host.latent_geometry(durs_all[ids2] / np.float32(1.05), a.sample_rate, a.base_chunk_size, a.chunk_compress_factor, a.latent_dim)
+    eng_bf16.batch_upload(tid2, mask2, sttl2, sdp2, duration_override=durs_all[ids2], utt_ids=ids2)
+    eng_bf16.batch_run(5, 1.05, 1234)
+    pcm2, dur2 = eng_bf16.batch_fetch_pcm16()
+    np.testing.assert_allclose(dur2, dur[ids2], rtol=1e-6)
+    worst = (0.0, 0.0)
     for j, i in enumerate(ids2):
-        n = lens2[j]
-        mx, rms = rel_err(lat2[j, :, :n], keep[int(i)][:, :n])
-        assert mx < 4e-2 and rms < 8e-3, (int(i), mx, rms)  # bf16: other tile shapes / kernel forms, same math
-        assert np.all(keep[int(i)][:, n:] == 0)
+        n = ns[i]
+        x, y = pcm[i, :n].astype(np.float64), pcm2[j, :n].astype(np.float64)
+        rms = np.sqrt(np.mean(x ** 2)) + 1.0
+        mx, er = np.abs(x - y).max() / rms, np.sqrt(np.mean((x - y) ** 2)) / rms
+        worst = (max(worst[0], mx), max(worst[1], er))
+        # bf16, other tile shapes / kernel forms on both sides of the row thresholds, same math: the waveform of up to 20 s agrees to
+        # a few percent rms (the latent to 4e-2 / 8e-3, tests/test_gpu_batch_invariance.py; the vocoder's 10 blocks carry it on)
+        assert mx < 0.6 and er < 0.02, (int(i), mx, er)
+    print(f"C4 another composition, PCM: worst max {worst[0]:.3f} rms {worst[1]:.4f} of the utterance's rms")
 
 
 def test_c3_full_size_bench_workload_matches_oracle(ref, eng_f32, eng_bf16, eng_f16):

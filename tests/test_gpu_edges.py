@@ -86,14 +86,13 @@ def test_pcm16_fetch_matches_reference_wav_conversion(eng):
     # the host-side encoder (C++) agrees with the oracle on clipped data too
     assert host.wav_bytes(wav2.ravel(), a.sample_rate) == host_ref.wav_bytes(wav2.ravel(), a.sample_rate)
     # device-side copy into a strided buffer (the RCCL gather payload of bench.py / supertonic_amd.dist): same samples
-    import torch
+    from hip_util import DeviceBuffer
     B, W = wav.shape
     for stride in (W + 8, W + 3):  # 16-byte aligned rows (vector path) and an odd stride (scalar path)
-        t = torch.full((B, stride), -7, dtype=torch.int16, device="cuda:0")
-        torch.cuda.synchronize()
-        eng.batch_copy_pcm16_device(t.data_ptr(), stride)
+        t = DeviceBuffer(np.full((B, stride), -7, dtype=np.int16))
+        eng.batch_copy_pcm16_device(t.ptr, stride)
         eng.sync()
-        got = t.cpu().numpy()
+        got = t.to_host()
         assert np.array_equal(got[:, :W], ref_pcm) and np.all(got[:, W:] == -7)
 
 
