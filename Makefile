@@ -38,8 +38,22 @@ build/pk_probe: tools/probe/pk_probe.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -o $@ $<
 
+# Sanitizer build of the host-side parsers (CPU only; no GPU sanitizer exists on this pool): everything under csrc/host/ that reads
+# caller-supplied files and strings — the protobuf reader, the graph binder, the JSON reader, the text frontend, the voice-style loader —
+# as a host-only shared library (tests/test_host_asan_cpu.py runs the host test files against it: STN_LIB, STN_HOST_ONLY=1, libasan
+# preloaded) and a corpus driver (tools/host_fuzz.cpp).  tts_host.cpp (TextToSpeech: calls the engine ABI) is not part of it.
+ASAN_FLAGS := -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -fPIC -Iinclude -Wall
+HOST_ONLY  := $(filter-out $(CSRC)/host/tts_host.cpp,$(wildcard $(CSRC)/host/*.cpp))
+host-asan: build_asan/libstn_host_asan.so build_asan/host_fuzz
+build_asan/libstn_host_asan.so: $(HOST_ONLY) $(HDRS)
+	@mkdir -p build_asan
+	g++ $(ASAN_FLAGS) -shared -o $@ $(HOST_ONLY)
+build_asan/host_fuzz: tools/host_fuzz.cpp $(HOST_ONLY) $(HDRS)
+	@mkdir -p build_asan
+	g++ $(ASAN_FLAGS) -o $@ tools/host_fuzz.cpp $(HOST_ONLY)
+
 clean:
-	rm -rf build supertonic_amd/libstn.so supertonic_amd/example_native
+	rm -rf build build_asan supertonic_amd/libstn.so supertonic_amd/example_native
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean probe
+.PHONY: all oracle clean probe host-asan

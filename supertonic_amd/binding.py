@@ -83,11 +83,16 @@ def load():
     # resolves against the runtime that is already loaded).  The multi-GPU helpers (supertonic_amd.dist) and bench.py need
     # torch in the same process, so when torch is installed it is imported before the library (STN_NO_TORCH_PRELOAD=1 skips this).
     import sys
-    if "torch" not in sys.modules and os.environ.get("STN_NO_TORCH_PRELOAD") != "1":
+    if "torch" not in sys.modules and os.environ.get("STN_NO_TORCH_PRELOAD") != "1" and os.environ.get("STN_HOST_ONLY") != "1":
         import importlib.util
         if importlib.util.find_spec("torch") is not None:
             import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
+    if os.environ.get("STN_HOST_ONLY") == "1":
+        # the sanitizer build of the host-side parsers (make host-asan, STN_LIB=build_asan/libstn_host_asan.so): include/stn_host.h
+        # only, no engine entry points to declare (supertonic_amd.host sets its own signatures)
+        _LIB = L
+        return L
     vp, ci, cu64, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
     L.stn_hip_versions.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.stn_ffn_fused_forms.argtypes = [ci, ci, ci]
