@@ -127,10 +127,20 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * latent frames each utterance owns (sum of lengths rows), 0 = padded [b*L + t] rows with the padding masked to zero after
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
-/* Cross-attention blocks of the vector estimator: 0 = four launches (LayerNorm, q projection, attention, output projection +
- * residual), 1 = one fused launch per block, 2 = two launches cut behind the q projection (the fused kernel's phases; both 16-bit
- * modes only, contexts of <= 128 keys; longer contexts take the four launches).  Same result up to the rounding of the 16-bit
- * intermediates; 1 and 2 give the same bits (tests/test_gpu_xattn.py).  Other values: 0. */
+/* GELU form of the loaded model: 0 = erf (default), 1 = the tanh approximation 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3))).
+ * stn_load_dir sets it from how the graphs spell the activation (Gelu / Erf: 0; Tanh inside the GELU pattern or Gelu approximate="tanh":
+ * 1); a synthetic-weight engine that should compute the tanh form sets it here.  fp32 and f16 engines follow it exactly (the fused K4
+ * kernels of the 16-bit modes compute the exp2 = tanh form either way, bf16 stores the tanh-form shortcut: DESIGN.md 5d). */
+int stn_set_gelu_form(stn_handle* h, int tanh_form);
+int stn_get_gelu_form(const stn_handle* h);
+/* Cross-attention blocks of the vector estimator: 3 (default) = head-split: fold_ln (or LayerNorm) + ONE launch per block that
+ * computes, per (utterance pair, head), the q projection, its rotation, the attention and the head's share of the output projection
+ * and leaves it as a 16-bit per-head partial sum which the next ConvNeXt block's fold adds to the residual stream in head order
+ * (kernels_xattn_hs.hip; 16-bit modes, packed rows with K4-split active, <= 256 frames per utterance, contexts of <= 128 keys: other
+ * shapes take the four launches); 0 = four launches (LayerNorm, q projection, attention, output projection + residual); 1 = one fused
+ * launch per utterance tile, 2 = the same cut in two behind the q projection (kernels_xattn.hip; measured at parity / slower).  Same
+ * result up to the rounding of the 16-bit intermediates (3: and of the per-head partial sums); 1 and 2 give the same bits
+ * (tests/test_gpu_xattn.py).  Other values: 0. */
 int stn_set_fused_xattn(stn_handle* h, int on);
 /* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
  * activation never leaves the registers (bf16 and f16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip
@@ -138,9 +148,10 @@ int stn_set_fused_xattn(stn_handle* h, int on);
  * Bit mask over the stages: 1 = vocoder, 2 = vector estimator, 4 = text encoder / duration predictor, 8 = the estimator's blocks as
  * K4-split (see stn_set_fused_ffn_min_rows); 0 = never.  The default (9) is the set of stages where a form measured faster on
  * MI355X.
- * WHAT IS AND IS NOT BIT-IDENTICAL.  Which kernel a block runs is decided by the launch's row count (these thresholds; also split-K
- * for small exact-fp32 GEMMs and the attention grid shape), so an utterance synthesized alone and the same utterance inside a large
- * batch may run different kernels: they agree to rounding (K4 vs two launches: fp32 summation order and, in f16, the exp2- vs
+ * WHAT IS AND IS NOT BIT-IDENTICAL.  Which kernel a block runs is decided by the launch's row count (these thresholds; the K4-split of
+ * the estimator's blocks is 12 ways up to 2048 packed rows and 4 ways beyond; also split-K for small exact-fp32 GEMMs and the attention
+ * grid shape), so an utterance synthesized alone, a small shard of a batch (e.g. 16 utterances per GPU of a strong-scaling run: below
+ * 2048 rows) and the same utterance inside a large batch may run different kernels: they agree to rounding (K4 vs two launches: fp32 summation order and, in f16, the exp2- vs
  * erf-form GELU; K4-split: 16-bit partial sums), with identical predicted durations to 1e-5 and identical latent lengths
  * (tests/test_gpu_batch_invariance.py holds recorded bounds).  Within one kernel regime a row's result does not depend on the
  * number of rows, their order or their position in the launch: packed vs trimmed vs dense vocoder rows, graph replay vs eager and

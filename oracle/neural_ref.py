@@ -68,6 +68,11 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
+def set_gelu_tanh(on):
+    """Process-wide GELU form of the oracle: False = erf (default), True = the tanh approximation (graphs that spell GELU with Tanh)."""
+    lib().stnref_set_gelu_tanh(int(bool(on)))
+
+
 class RefModel:
     """fp32 CPU restatement of the four stages on synthetic weights (arch, seed)."""
 

@@ -220,7 +220,14 @@ int64_t stnref_tensor(const stnref_model* m, const char* name, float* out, int64
 
 static float* falloc(int64_t n) { float* p = malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); if (!p) abort(); return p; }
 
-static float gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+/* GELU: the erf form (torch.nn.GELU()) or, when the graphs being checked spell it with Tanh (stnref_set_gelu_tanh), the tanh
+ * approximation 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))).  Process-wide switch of this test library. */
+static int g_gelu_tanh = 0;
+void stnref_set_gelu_tanh(int on) { g_gelu_tanh = on != 0; }
+static float gelu(float x) {
+    if (g_gelu_tanh) return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
 static float silu(float x) { return x / (1.0f + expf(-x)); }
 
 /* Y[M][N] = X[M][K] . W[N][K]^T + b   (k-ordered fp32 accumulation) */

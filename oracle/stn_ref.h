@@ -11,6 +11,7 @@ extern "C" {
 typedef struct stnref_model stnref_model;
 
 void stnref_set_threads(int n);
+void stnref_set_gelu_tanh(int on);  /* process-wide: 0 = erf form (default), 1 = the tanh approximation */
 int stnref_get_threads(void);
 stnref_model* stnref_create(const stn_arch* a, uint64_t seed);
 void stnref_destroy(stnref_model* m);

@@ -159,6 +159,7 @@ int stn_load_dir(stn_handle* h, const char* onnx_dir) {
                     if (it == gb.tensors.end()) throw std::runtime_error("graph binding: no initializer was bound to tensor \"" + name + "\"");
                     return stn::graphbind::fetch(it->second, name, rows, cols);
                 });
+                h->eng->set_gelu_form(gb.gelu == "tanh");  // the activation the graphs compute (fp32 / f16 follow it exactly)
                 h->err = gb.notes;  // readable through stn_last_error after a successful load
                 return STN_OK;
             }
@@ -276,6 +277,8 @@ int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_m
 int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows() : 0; }
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
+int stn_set_gelu_form(stn_handle* h, int tanh_form) { STN_TRY(h, { h->eng->set_gelu_form(tanh_form); }) }
+int stn_get_gelu_form(const stn_handle* h) { return h ? h->eng->gelu_form() : STN_ERR_INVALID; }
 int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_xattn(on); }) }
 int stn_set_fused_ffn(stn_handle* h, int mask) { STN_TRY(h, { need(mask >= 0 && mask <= 15, "stage mask must be in 0..15"); h->eng->set_fused_ffn(mask); }) }
 int stn_set_fused_ffn_min_rows(stn_handle* h, int64_t k4_rows, int64_t split_rows) { STN_TRY(h, { h->eng->set_fused_ffn_min_rows(k4_rows, split_rows); }) }

@@ -569,8 +569,8 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     const auto fw = ffn_w_.find(p.pw1.w.as(dt_));
     // K4-split (the estimator at batch size: 59 slabs of 128 rows cannot fill 256 CUs, and a workgroup that streams both matrices
     // for 128 rows is ingest-bound): four workgroups per slab, each over a quarter of the hidden units (a quarter of the weight
-    // stream), 16-bit partial sums; b2, layer scale, residual and time vector are applied by the next reader of x.  The split is a
-    // function of the block's shape only.  Packed rows only (the fold kernels index sequences through row_off).
+    // stream), 16-bit partial sums; b2, layer scale, residual and time vector are applied by the next reader of x.  How many
+    // ways is ffn_split_choose's decision on the launch's row count (fs->S).  Packed rows only (the fold kernels index sequences through row_off).
     if (fs && fs->S > 1 && rg && (fused_ffn_ & 8) && stage_bit == 2 && fw != ffn_w_.end() && fw->second.wsplit[split_slot(fs->S)] && M >= ffn_split_min_rows_ &&
         M * C * 2 < 0x7FFFFFFFll && fold_dwconv_ln_supported(C, k, 1 << std::max(0, a_.ve_dilated - 1))) {
         FfnArgs fa;
@@ -605,7 +605,7 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     }
     void* u = act_alloc(M * hid);
     Epilogue e1;
-    e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
+    e1.mode = EPI_STORE; e1.act = gelu_act_; e1.out_dtype = dt_; e1.out = u; e1.ldo = hid;
     // a hidden activation larger than half the 256 MB Infinity Cache (the vocoder's: 245 MB per block at C3) is written once:
     // non-temporal stores keep it from evicting the residual stream and the LayerNorm output (vo.pw1 181 -> 162 us).  Measured
     // and rejected: non-temporal A loads in pw2 (+9 %: each panel is read by two column tiles); running pw1/pw2 slab by slab
@@ -699,7 +699,7 @@ void Engine::duration_dev(int B, int Lt, const int64_t* ids, const float* style_
     float* pooled = f32_alloc((int64_t)B * C);
     launch_masked_mean(s_, F32, xn, B, Lt, C, tlen, pooled, toff);
     float* h = f32_alloc((int64_t)B * C);
-    Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = F32; e1.out = h; e1.ldo = C;
+    Epilogue e1; e1.mode = EPI_STORE; e1.act = gelu_act_; e1.out_dtype = F32; e1.out = h; e1.ldo = C;
     gemm("gemm_small_f32", F32, pooled, C, linear("dp.fc1"), B, e1);
     Epilogue e2; e2.mode = EPI_STORE; e2.out_dtype = F32; e2.out = dur; e2.ldo = 1;
     gemm("gemm_small_f32", F32, h, C, linear("dp.fc2"), B, e2);
@@ -728,7 +728,7 @@ void Engine::text_enc_dev(int B, int Lt, const int64_t* ids, const float* style_
         void* u = act_alloc(M * a.te_ffn);
         const LNorm ln = lnorm(p + ".ffn_ln");
         launch_layernorm(s_, dt_, x, M, C, ln.g, ln.b, a.ln_eps, xn);
-        Epilogue e1; e1.mode = EPI_STORE; e1.act = ACT_GELU; e1.out_dtype = dt_; e1.out = u; e1.ldo = a.te_ffn;
+        Epilogue e1; e1.mode = EPI_STORE; e1.act = gelu_act_; e1.out_dtype = dt_; e1.out = u; e1.ldo = a.te_ffn;
         gemm("gemm_pw1_gelu", dt_, xn, C, linear(p + ".ffn1"), (int)M, e1);
         Epilogue e2; e2.mode = EPI_RESID; e2.resid = x; e2.ldo = C; e2.len = rmask; e2.L = Lt;
         gemm("gemm_pw2_resid", dt_, u, a.te_ffn, linear(p + ".ffn2"), (int)M, e2);

@@ -177,6 +177,12 @@ class Engine {
     void set_vocoder_mode(bool length_aware) { vo_ragged_ = length_aware; }
     // vector-estimator row layout in batch_run: packed rows (default) or the padded [b*L + t] rows (tests compare the two)
     void set_packed_rows(bool on) { packed_ve_ = on; }
+    // GELU form of the loaded model: 0 = erf (the default: torch.nn.GELU()), 1 = the tanh approximation.  stn_load_dir sets it from how the
+    // graphs spell the activation (graph_bind Result::gelu); fp32 and f16 results follow it exactly, bf16 stores take the tanh-form
+    // shortcut for both (|difference to erf| <= 5e-4, below half a bf16 ulp where it matters), and the fused K4 kernels compute the
+    // exp2 (= tanh) form in both 16-bit modes.
+    void set_gelu_form(int tanh_form) { if ((tanh_form != 0) != (gelu_act_ == ACT_GELU_TANH)) { sync(); drop_graphs(); } gelu_act_ = tanh_form ? ACT_GELU_TANH : ACT_GELU; }
+    int gelu_form() const { return gelu_act_ == ACT_GELU_TANH ? 1 : 0; }
     // cross-attention blocks of the estimator as ONE launch each (kernels_xattn.hip) instead of four
     void set_fused_xattn(int mode) { fused_xattn_ = mode < 0 || mode > 3 ? 0 : mode; }  // 0: four launches, 1: one, 2: two (cut behind the q projection), 3: head-split (fold_ln + one launch, kernels_xattn_hs.hip)
     // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
@@ -360,6 +366,7 @@ class Engine {
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int64_t ffn_split_min_rows_ = 1;     // K4-split from this many rows on (with the slab staged through LDS one utterance gains too: 20.0 vs 21.4 us per block); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
+    int gelu_act_ = ACT_GELU;
     int fused_xattn_ = 3;  // cross-attention blocks of the estimator: 3 head-split (fold_ln + one launch, kernels_xattn_hs.hip; the default), 0 four launches,
                            // 1 one launch per utterance tile, 2 the same cut in two (kernels_xattn.hip); STN_XATTN=<0..3> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;

@@ -79,7 +79,22 @@ std::vector<Tok> weighted_nodes(const Model& m, const std::string& file, std::st
         if (gelu_form) {  // how the graph writes the activation (Result::gelu)
             if (n.op_type == "Gelu") { if (gelu_form->empty()) *gelu_form = n.attr_s("approximate", "none") == "tanh" ? "tanh" : "op"; }
             else if (n.op_type == "Erf") *gelu_form = "erf";
-            else if (n.op_type == "Tanh" && *gelu_form != "erf") *gelu_form = "tanh";
+            else if (n.op_type == "Tanh" && *gelu_form != "erf" && !n.outputs.empty()) {
+                // only the Tanh of 0.5 x (1 + tanh(..)): its output goes into an Add whose result goes into a Mul (a Tanh anywhere else in
+                // the graph — a gate, a bounded output — says nothing about the activation)
+                bool in_gelu = false;
+                for (const Node& add : m.nodes) {
+                    if (add.op_type != "Add" || add.outputs.empty()) continue;
+                    bool takes = false;
+                    for (const std::string& in : add.inputs) takes = takes || in == n.outputs[0];
+                    if (!takes) continue;
+                    for (const Node& mul : m.nodes) {
+                        if (mul.op_type != "Mul") continue;
+                        for (const std::string& in : mul.inputs) in_gelu = in_gelu || in == add.outputs[0];
+                    }
+                }
+                if (in_gelu) *gelu_form = "tanh";
+            }
         }
         if (n.op_type == "Gather") {
             const Tensor* w = get(n, 0);
@@ -496,8 +511,8 @@ Result bind(const stn_arch& base, const Model& dpm, const Model& tem, const Mode
         p.done();
     }
     if (r.gelu == "tanh")
-        r.notes += "the graphs spell GELU with Tanh (the tanh approximation): this engine computes the erf form in fp32 and f16 and the tanh form in bf16 "
-                   "(|difference| <= 5e-4 absolute, kernels_dev.hpp); ";
+        r.notes += "the graphs spell GELU with Tanh (the tanh approximation): the engine computes that form (stn_set_gelu_form 1: exact in fp32 and f16, "
+                   "the exp2 shortcut of the same function in bf16, kernels_dev.hpp); ";
     return r;
 }
 

@@ -62,7 +62,7 @@ inline void stn_check_hip(hipError_t e, const char* what) {
 enum DType : int { F32 = 0, BF16 = 1, F16 = 2 };  // F16: IEEE half operands / activations (v_mfma_f32_32x32x16_f16), fp32 accumulate
 __host__ __device__ inline bool is_half(int dt) { return dt == BF16 || dt == F16; }  // 2-byte storage
 typedef _Float16 f16_t;                                          // storage type of the F16 mode (bf16 is raw uint16_t)
-enum ActFn : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+enum ActFn : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_GELU_TANH = 3 };  // GELU: erf form; GELU_TANH: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))
 
 // GEMM epilogue description:  acc[m][n] = sum_k A[m][k] * W[n][k]
 enum EpiMode : int {
@@ -132,10 +132,13 @@ struct FfnArgs {
     int64_t part_stride = 0;                      // elements between two splits (= padded rows * C)
 };
 bool ffn_fused_supported(int dtype, int C, int I);
-// hidden-split factor of the K4-split form for this block shape (0: not supported).  A function of (C, I) ONLY: a row's result
-// must not depend on the number of rows in the launch.
+// whether the block shape has a K4-split form at all (0: no; > 1: yes)
 int ffn_split_factor(int dtype, int C, int I);
-// splits a block shape can run with (4, 12, 24: I / 32 / S hidden tiles per workgroup, an even number), and the one a launch of M rows takes
+// splits a block shape can run with (4, 12, 24: I / 32 / S hidden tiles per workgroup, an even number), and the one a launch of M rows
+// takes: 12 ways up to 16 slabs (2048 rows), 4 ways beyond.  The split is a function of the launch's ROW COUNT, so the order in which a
+// row's 16-bit partial sums are added depends on how many rows the launch has: results on either side of the boundary (an utterance
+// alone, a 16-utterance shard of a strong-scaling run, the unsharded batch) agree to rounding, not bit for bit (include/stn.h,
+// tests/test_gpu_ffn.py::test_ffn_split_regimes_agree_to_rounding: 2 048 rows against 2 176)
 bool ffn_split_valid(int dtype, int C, int I, int S);
 int ffn_split_choose(int dtype, int C, int I, int64_t M);
 inline int64_t ffn_split_rows(int64_t M) { return (M + 127) / 128 * 128; }

@@ -33,8 +33,15 @@ __device__ __forceinline__ float gelu_f(float x) {
     const float erf_v = x < 0.f ? -erf_abs : erf_abs;
     return 0.5f * x * (1.0f + erf_v);
 }
+// the tanh form of GELU, 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x sigmoid(2 sqrt(2/pi) x (1 + 0.044715 x^2)), in full fp32
+// precision: what a graph that spells GELU with Tanh (or Gelu approximate="tanh") computes (fp32 / f16 outputs; bf16 outputs take
+// gelu_bf16_f below, the same function through v_exp / v_rcp)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    return x / (1.0f + expf(-1.5957691216057308f * x * (1.0f + 0.044715f * x * x)));
+}
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == ACT_GELU) return gelu_f(v);
+    if (act == ACT_GELU_TANH) return gelu_tanh_f(v);
     if (act == ACT_SILU) return v / (1.0f + expf(-v));
     return v;
 }
@@ -46,7 +53,7 @@ __device__ __forceinline__ float gelu_bf16_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 __device__ __forceinline__ float act_out_f(float v, int act, bool to_bf16) {
-    if (act == ACT_GELU && to_bf16) return gelu_bf16_f(v);
+    if ((act == ACT_GELU || act == ACT_GELU_TANH) && to_bf16) return gelu_bf16_f(v);
     return act_f(v, act);
 }
 // bias + activation + row mask on an 8-column group; the activation kind is resolved ONCE per group (a per-element
@@ -55,12 +62,15 @@ __device__ __forceinline__ void act8(float (&v)[8], const float (&bias)[8], int 
     if (act == ACT_NONE) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (v[j] + bias[j]) * keep;
-    } else if (act == ACT_GELU && to_bf16) {
+    } else if ((act == ACT_GELU || act == ACT_GELU_TANH) && to_bf16) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_bf16_f(v[j] + bias[j]) * keep;
     } else if (act == ACT_GELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j] + bias[j]) * keep;
+    } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_tanh_f(v[j] + bias[j]) * keep;
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float t = v[j] + bias[j]; v[j] = t / (1.0f + expf(-t)) * keep; }

@@ -658,6 +658,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tiled_kernel(const void* __r
                 if (e.act == ACT_GELU) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = F16 ? gelu_f(v[i]) : gelu_bf16_f(v[i]);  // half keeps 11 bits: erf form
+                } else if (e.act == ACT_GELU_TANH) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = F16 ? gelu_tanh_f(v[i]) : gelu_bf16_f(v[i]);
                 } else if (e.act == ACT_SILU) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = v[i] / (1.0f + expf(-v[i]));

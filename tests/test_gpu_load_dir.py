@@ -122,9 +122,10 @@ def test_load_dir_error_paths(tmp_path):
         eng.load_dir(str(tmp_path))
 
 
-def _same_as_synthetic(a, seed, eng, dtype="f32"):
+def _same_as_synthetic(a, seed, eng, dtype="f32", gelu_tanh=False):
     synth = binding.Engine(0, dtype)
     synth.load_synthetic(a, seed)
+    synth.set_gelu_form(gelu_tanh)
     assert eng.param_count == synth.param_count
     ids, mask, sttl, sdp = make_inputs(a, 2, 12, [12, 7], seed=2)
     durs = np.array([0.3, 0.12], np.float32)
@@ -225,10 +226,21 @@ def test_exporter_variants_load_bit_identically(tmp_path, variants):
     build_graph_dir(tmp_path, a, ref.tensor, variants=variants)
     eng = binding.Engine(0, "f32")
     eng.load_dir(str(tmp_path))
-    _same_as_synthetic(a, 7, eng)
-    _against_oracle(a, ref, eng, "f32")
-    if variants.get("gelu") == "tanh":
-        assert "Tanh" in eng.last_error()
+    tanh = variants.get("gelu") == "tanh"
+    assert eng.gelu_form == (1 if tanh else 0)  # the loaded engine computes the activation the graphs spell
+    from oracle import neural_ref
+    try:
+        neural_ref.set_gelu_tanh(tanh)           # ... and is held to the oracle computing that same form,
+        _same_as_synthetic(a, 7, eng, gelu_tanh=tanh)   # and to a synthetic engine switched to it
+        _against_oracle(a, ref, eng, "f32")
+        if tanh:
+            assert "Tanh" in eng.last_error()
+            # the erf form is a DIFFERENT function at fp32 resolution: an engine left on erf must not pass as equal
+            eng.set_gelu_form(0)
+            with pytest.raises(AssertionError):
+                _same_as_synthetic(a, 7, eng, gelu_tanh=True)
+    finally:
+        neural_ref.set_gelu_tanh(False)
 
 
 def test_wave_head_as_transposed_convolution_loads_like_the_projection(tmp_path):

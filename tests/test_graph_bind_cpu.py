@@ -179,3 +179,25 @@ def test_graph_io_names_are_checked(tmp_path):
     build_graph_dir(tmp_path, a, _zeros(a), io_overrides={"vo": (["z"], ["wav_tts"])})
     with pytest.raises(OSError, match=r"vocoder\.onnx: graph inputs are \{z\}, the host feeds \{latent\}"):
         host.bind_graphs(str(tmp_path))
+
+
+def test_a_tanh_outside_the_gelu_pattern_is_not_a_gelu(tmp_path):
+    """only the Tanh of 0.5 x (1 + tanh(..)) — Tanh -> Add -> Mul — names the activation; a Tanh anywhere else (here: a
+    bounded output behind the duration predictor's last projection) leaves the form as the Gelu nodes say."""
+    import onnx_graphs
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    orig = onnx_graphs.Graph.model
+
+    def model_with_stray_tanh(self):
+        if self.stage == "dp":
+            self.cur = self.op("Tanh", [self.cur])  # feeds the output Identity, not an Add
+        return orig(self)
+
+    onnx_graphs.Graph.model = model_with_stray_tanh
+    try:
+        build_graph_dir(tmp_path, a, ref.tensor)
+    finally:
+        onnx_graphs.Graph.model = orig
+    g = host.bind_graphs(str(tmp_path))
+    assert g["gelu"] == "op" and "Tanh" not in g["notes"]
