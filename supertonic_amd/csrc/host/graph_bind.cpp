@@ -38,6 +38,11 @@ struct Tok {
     bool bias_bcast = false;      // the bias is one value for all `out` outputs (one-channel ConvTranspose head)
     std::string out_name;         // SCALE: the value it produces (a decomposed LayerNorm's beta Add refers to it)
     bool norm_scale = false;      // SCALE whose input is a normalised value (x - mean) / sqrt(var + eps): the gamma of a decomposed LayerNorm
+    // LINEAR whose result is cut into equal parts by a Split (or by Slices) on the channel axis — a fused q|k|v / k|v projection:
+    int split_parts = 0;          // number of parts (0: no Split / Slice consumes the projection)
+    std::string split_where;      // the Split / Slice node(s)
+    std::string split_roles;      // what each part feeds, in part order: 'q', 'k', 'v' (or '?': not traceable to the attention's MatMuls)
+    std::string split_err;        // why the cut is not the row-block layout the binder assumes (axis, sizes); empty = fine
 };
 
 std::string dims_str(const Tensor* t) {
@@ -193,6 +198,135 @@ std::vector<Tok> weighted_nodes(const Model& m, const std::string& file, std::st
         if (t.kind == SCALE && !t.out_name.empty()) scale_tok[t.out_name] = (int)toks.size();
         toks.push_back(t);
     }
+    // ---- fused projections: who cuts a projection's result, on which axis, into what sizes, and which attention operand each part becomes.
+    // The binder assigns the row blocks of a 3C / 2C projection to q | k | v in part order: that is only right when the graph's own Split
+    // (or Slices) cuts the LAST axis into equal blocks and hands them to the attention in that order.
+    {
+        std::unordered_map<std::string, std::vector<int>> cons;   // value -> nodes that read it
+        std::unordered_map<std::string, int> made_at;             // value -> node that writes it
+        for (size_t ni = 0; ni < m.nodes.size(); ++ni) {
+            for (const std::string& in : m.nodes[ni].inputs) cons[in].push_back((int)ni);
+            for (const std::string& o : m.nodes[ni].outputs) made_at[o] = (int)ni;
+        }
+        auto consumers = [&](const std::string& v) -> const std::vector<int>& { static const std::vector<int> none; auto it = cons.find(v); return it == cons.end() ? none : it->second; };
+        auto is_act_matmul = [&](const Node& n) { return n.op_type == "MatMul" && n.inputs.size() == 2 && !init.count(n.inputs[0]) && !init.count(n.inputs[1]); };
+        // nearest activation x activation MatMul downstream of a value, and the operand slot the value's lineage enters it through
+        auto first_matmul = [&](const std::string& start, int* slot) -> int {
+            std::vector<std::string> frontier{start};
+            std::unordered_map<std::string, bool> seen;
+            for (int visited = 0; !frontier.empty() && visited < 256;) {
+                std::vector<std::string> next;
+                for (const std::string& v : frontier) {
+                    if (seen[v]) continue;
+                    seen[v] = true; ++visited;
+                    for (int ci : consumers(v)) {
+                        const Node& c = m.nodes[ci];
+                        if (is_act_matmul(c)) { *slot = c.inputs[0] == v ? 0 : 1; return ci; }
+                        if (c.op_type == "Softmax") continue;  // (a part never reaches the attention through a Softmax)
+                        for (const std::string& o : c.outputs) next.push_back(o);
+                    }
+                }
+                frontier.swap(next);
+            }
+            return -1;
+        };
+        auto softmax_downstream = [&](int mm) {  // the scores MatMul: its result reaches a Softmax before any other MatMul
+            std::vector<std::string> frontier(m.nodes[mm].outputs.begin(), m.nodes[mm].outputs.end());
+            for (int depth = 0; depth < 8 && !frontier.empty(); ++depth) {
+                std::vector<std::string> next;
+                for (const std::string& v : frontier)
+                    for (int ci : consumers(v)) {
+                        if (m.nodes[ci].op_type == "Softmax") return true;
+                        if (m.nodes[ci].op_type == "MatMul") continue;
+                        for (const std::string& o : m.nodes[ci].outputs) next.push_back(o);
+                    }
+                frontier.swap(next);
+            }
+            return false;
+        };
+        auto softmax_upstream = [&](int mm, int slot) {  // the P V MatMul: operand `slot` comes out of a Softmax
+            std::vector<std::string> frontier{m.nodes[mm].inputs[slot]};
+            for (int depth = 0; depth < 6 && !frontier.empty(); ++depth) {
+                std::vector<std::string> next;
+                for (const std::string& v : frontier) {
+                    auto it = made_at.find(v);
+                    if (it == made_at.end()) continue;
+                    const Node& pn = m.nodes[it->second];
+                    if (pn.op_type == "Softmax") return true;
+                    if (pn.op_type == "MatMul") continue;
+                    for (const std::string& in : pn.inputs) next.push_back(in);
+                }
+                frontier.swap(next);
+            }
+            return false;
+        };
+        std::unordered_map<int, std::string> tok_value;  // LINEAR token -> the last value it was seen to produce (behind its bias Add)
+        for (const auto& kv : producer) {
+            auto it = tok_value.find(kv.second);
+            if (it == tok_value.end() || made_at[kv.first] > made_at[it->second]) tok_value[kv.second] = kv.first;
+        }
+        for (auto& tv : tok_value) {
+            Tok& t = toks[tv.first];
+            std::string cur = tv.second;
+            for (int hop = 0; hop < 4; ++hop) {  // Transpose / Cast / Identity between the projection and its cut
+                const std::vector<int>& cs = consumers(cur);
+                if (cs.size() != 1) break;
+                const Node& c = m.nodes[cs[0]];
+                if ((c.op_type != "Transpose" && c.op_type != "Cast" && c.op_type != "Identity") || c.outputs.empty()) break;
+                cur = c.outputs[0];
+            }
+            struct Part { std::string value; int64_t start; };
+            std::vector<Part> parts;
+            const std::vector<int>& cs = consumers(cur);
+            std::vector<int64_t> sizes;
+            int64_t axis = -1;
+            bool all_slices = cs.size() >= 2;
+            for (int ci : cs) all_slices = all_slices && m.nodes[ci].op_type == "Slice";
+            if (cs.size() == 1 && m.nodes[cs[0]].op_type == "Split") {
+                const Node& sp = m.nodes[cs[0]];
+                t.split_where = "node #" + std::to_string(cs[0]) + " Split '" + sp.name + "'";
+                axis = sp.attr_i("axis", 0);
+                if (const auto* a = sp.attr("split")) sizes = *a;
+                else if (const Tensor* st = get(sp, 1)) { if (st->data_type == onnx::INT64) for (float f : onnx::to_float(*st)) sizes.push_back((int64_t)f); }
+                int64_t at = 0;
+                for (size_t j = 0; j < sp.outputs.size(); ++j) { parts.push_back({sp.outputs[j], at}); at += j < sizes.size() ? sizes[j] : 0; }
+            } else if (all_slices) {
+                t.split_where = std::to_string(cs.size()) + " Slice nodes behind " + t.where;
+                for (int ci : cs) {
+                    const Node& sl = m.nodes[ci];
+                    const Tensor *st = get(sl, 1), *en = get(sl, 2), *ax = get(sl, 3);
+                    if (!st || !en || sl.outputs.empty() || st->numel() != 1 || en->numel() != 1) { t.split_err = "node #" + std::to_string(ci) + " Slice '" + sl.name + "': starts / ends are not single constants"; break; }
+                    const int64_t s0 = (int64_t)onnx::to_float(*st)[0], e0 = (int64_t)onnx::to_float(*en)[0];
+                    if (ax && ax->numel() == 1) axis = (int64_t)onnx::to_float(*ax)[0];
+                    parts.push_back({sl.outputs[0], s0});
+                    sizes.push_back(e0 - s0);
+                }
+                // (parts in the order of their start offsets: that is the order of the row blocks)
+                std::vector<size_t> ord(parts.size());
+                for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
+                std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return parts[a].start < parts[b].start; });
+                std::vector<Part> p2; std::vector<int64_t> s2;
+                for (size_t j : ord) { p2.push_back(parts[j]); if (j < sizes.size()) s2.push_back(sizes[j]); }
+                parts.swap(p2); sizes.swap(s2);
+            } else continue;
+            t.split_parts = (int)parts.size();
+            if (t.split_err.empty() && axis != -1 && axis != 2)  // activations here are [batch, length, channels]
+                t.split_err = t.split_where + " cuts axis " + std::to_string(axis) + ", not the channel (last) axis";
+            if (t.split_err.empty() && !sizes.empty())
+                for (int64_t z : sizes)
+                    if (z * t.split_parts != t.out) { t.split_err = t.split_where + " cuts the " + std::to_string(t.out) + " channels into unequal parts"; break; }
+            for (const Part& pt : parts) {
+                int slot = 0;
+                const int mm = first_matmul(pt.value, &slot);
+                char role = '?';
+                if (mm >= 0) {
+                    if (softmax_upstream(mm, 1 - slot)) role = 'v';
+                    else if (softmax_downstream(mm)) role = slot == 0 ? 'q' : 'k';
+                }
+                t.split_roles.push_back(role);
+            }
+        }
+    }
     // a normalising scale that no beta followed is a LayerNorm without bias (beta = zeros)
     for (Tok& t : toks)
         if (t.kind == SCALE && t.norm_scale) { t.kind = LN; t.where += " (decomposed LayerNormalization without beta)"; }
@@ -290,6 +424,18 @@ struct Parser {
         auto h = [&](const Tok& tk) { if (!heads) heads = tk.heads; };
         auto fused = [&](const Tok& tk, std::initializer_list<const char*> parts) {
             const int n = (int)parts.size();
+            // the row blocks are only q | k | v in this order if the graph itself cuts the result that way: find the cut and hold it to that
+            std::string want;
+            for (const char* part : parts) want += part;
+            std::string problem;
+            if (tk.split_parts == 0) problem = "no Split (or set of Slices) consumes its result, so how the " + std::to_string(tk.out) + " rows divide into " + want + " cannot be read from the graph";
+            else if (!tk.split_err.empty()) problem = tk.split_err;
+            else if (tk.split_parts != n) problem = tk.split_where + " makes " + std::to_string(tk.split_parts) + " parts where " + std::to_string(n) + " (" + want + ") are needed";
+            else if (tk.split_roles != want)
+                problem = tk.split_where + " hands its parts to the attention as [" + tk.split_roles + "] ('?': not traceable to the score / value MatMuls); the binding of row blocks needs [" + want + "]";
+            if (!problem.empty())
+                throw std::runtime_error(file + ": fused " + want + " projection of block " + name + " (" + tk.where + ", " + std::to_string(tk.out) + " <- " + std::to_string(tk.in) + "): " + problem +
+                                         ". State the tensors in stn_weight_map.json instead (include/stn.h).");
             int j = 0;
             for (const char* part : parts) {
                 bind(name + "." + part + ".w", tk.w, tk.transposed, tk, j * c, n * c, c);

@@ -20,6 +20,9 @@ class Graph:
          ln   = "node" | "decomposed" | "decomposed_nobeta"   LayerNormalization as one node, or ReduceMean / Sub / Pow / ReduceMean / Add eps /
                                                               Sqrt / Div / Mul gamma / Add beta (beta dropped in the last form)
          qkv  = "separate" | "fused"                          q, k, v projections separately, or one 3C (self) / 2C (context k|v) projection + Split
+         cut  = "split" | "slices" | "swapped" | "axis1" | "none"   (qkv = "fused") how the fused projection's result is divided: one Split on the last axis, one
+                                                              Slice per part, a Split whose outputs reach the attention as k, q, v / v, k, a Split on the
+                                                              wrong axis, or no cut node at all (the last three are NOT the layout: the loader must say so)
          pw   = "mixed" | "matmul_transpose"                  projections in four encodings by position, or always Transpose -> MatMul -> Add -> Transpose
          gelu = "op" | "op_tanh" | "erf" | "tanh"             a Gelu node (approximate = none / tanh), or the Erf / Tanh formulas spelled out
          head = "linear" | "convtranspose" | "convtranspose_overlap"
@@ -29,7 +32,7 @@ class Graph:
 
     def __init__(self, stage, tensor, breaks, variants=None):
         self.stage, self.tensor, self.breaks = stage, tensor, breaks
-        self.var = dict(ln="node", qkv="separate", pw="mixed", gelu="op", head="linear")
+        self.var = dict(ln="node", qkv="separate", pw="mixed", gelu="op", head="linear", cut="split")
         self.var.update(variants or {})
         self.inits, self.nodes, self.n = [], [], 0
         self.cur = IO[stage][0][0]
@@ -162,15 +165,28 @@ class Graph:
         kv_src = self.cur if ctx is None else ctx
         split = lambda x: self.op("Reshape", [x, self.shape_const([0, 0, heads, C // heads])]) if with_heads else self.op("Identity", [x])
         cat = lambda parts, suf, shp: np.concatenate([self.w(f"{name}.{p_}.{suf}", shp) for p_ in parts], 0)
+        def cut(f, names):
+            """the fused projection's result f -> one value per name, by the `cut` variant"""
+            mode = self.var["cut"]
+            outs = [f + "_" + n_ for n_ in names]
+            if mode == "slices":  # one Slice per part, emitted in REVERSE order (the binder must go by the offsets, not by node order)
+                for j in reversed(range(len(names))):
+                    ins = [f] + [self.init("slice", np.array([v_], np.int64)) for v_ in (j * C, (j + 1) * C, -1)]
+                    self.nodes.append(ow.node("Slice", ins, [outs[j]], f"/{self.stage}/Slice_{len(self.nodes)}"))
+            elif mode == "none":
+                return [f] * len(names)
+            else:
+                o = list(reversed(outs)) if mode == "swapped" and len(outs) == 2 else ([outs[1], outs[0]] + outs[2:] if mode == "swapped" else outs)
+                self.nodes.append(ow.node("Split", [f], o, f"/{self.stage}/Split_{len(self.nodes)}", [ow.attr_int("axis", 1 if mode == "axis1" else -1)]))
+            return outs
+
         if self.var["qkv"] == "fused" and ctx is None:  # self-attention: ONE projection of 3C rows, split afterwards
             f = self.linear_wb(name + ".qkv", cat("qkv", "w", (C, C)), cat("qkv", "b", (C,)), self.cur, advance=False)
-            self.nodes.append(ow.node("Split", [f], [f + "_q", f + "_k", f + "_v"], f"/{self.stage}/Split_{len(self.nodes)}", [ow.attr_int("axis", -1)]))
-            q, k, v = split(f + "_q"), split(f + "_k"), split(f + "_v")
+            q, k, v = (split(x) for x in cut(f, "qkv"))
         elif self.var["qkv"] == "fused":  # cross-attention: q alone, k | v as ONE projection of the context
             q = split(self.linear(name + ".q", C, C, src=self.cur))
             f = self.linear_wb(name + ".kv", cat("kv", "w", (C, Cctx)), cat("kv", "b", (C,)), kv_src, advance=False)
-            self.nodes.append(ow.node("Split", [f], [f + "_k", f + "_v"], f"/{self.stage}/Split_{len(self.nodes)}", [ow.attr_int("axis", -1)]))
-            k, v = split(f + "_k"), split(f + "_v")
+            k, v = (split(x) for x in cut(f, "kv"))
         else:
             q = split(self.linear(name + ".q", C, C, src=self.cur))
             k = split(self.linear(name + ".k", C, Cctx, src=kv_src))

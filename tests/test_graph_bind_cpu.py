@@ -201,3 +201,29 @@ def test_a_tanh_outside_the_gelu_pattern_is_not_a_gelu(tmp_path):
         onnx_graphs.Graph.model = orig
     g = host.bind_graphs(str(tmp_path))
     assert g["gelu"] == "op" and "Tanh" not in g["notes"]
+
+
+def test_fused_projection_cut_by_slices_binds_like_a_split(tmp_path):
+    """One Slice per part (emitted in reverse node order): the parts are taken by their offsets, the roles by the MatMuls they reach."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    build_graph_dir(tmp_path, a, ref.tensor, variants=dict(qkv="fused", cut="slices"))
+    g = host.bind_graphs(str(tmp_path))
+    assert g["tensors"]["te.sa0.k.w"]["row0"] == a.te_dim and g["tensors"]["ve.m0.style.v.w"]["row0"] == a.ve_dim
+    for name in ("te.sa0.q.w", "te.sa0.k.w", "te.sa0.v.b", "ve.m0.text.k.w", "dp.st.v.w"):
+        np.testing.assert_array_equal(host.bound_tensor(str(tmp_path), name), ref.tensor(name), err_msg=name)
+
+
+@pytest.mark.parametrize("cut,needle", [("swapped", "hands its parts to the attention as ["), ("axis1", "not the channel (last) axis"),
+                                        ("none", "no Split (or set of Slices) consumes its result")])
+def test_fused_projection_that_is_not_cut_into_q_k_v_row_blocks_is_refused(tmp_path, cut, needle):
+    """a fused q|k|v / k|v projection is bound as row blocks [q; k; v] only when the graph's own Split says so — last
+    axis, equal parts, parts reaching the attention in that order.  Anything else fails with the node named instead of loading
+    silently with permuted weights."""
+    a = tiny_arch()
+    ref = RefModel(a, 7)
+    build_graph_dir(tmp_path, a, ref.tensor, variants=dict(qkv="fused", cut=cut))
+    with pytest.raises(OSError) as ei:
+        host.bind_graphs(str(tmp_path))
+    msg = str(ei.value)
+    assert needle in msg and "fused" in msg and "projection of block dp.st" in msg and "stn_weight_map.json" in msg, msg
