@@ -286,6 +286,19 @@ def main():
         fence()
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat))
+    # ---- the same lone batch on the critical path of a PREDICTED-duration run: the duration predictor, the device->host read of its
+    # result and the wait for it precede everything else (the forced-duration runs above skip the read: durations are known on the
+    # host).  Shapes stay the forced ones (stn_set_duration_read: synthetic weights predict meaningless lengths).
+    lat_pred = []
+    eng.set_duration_read(True)
+    for _ in range(min(5, max(2, args.steps)) + 1):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        lat_pred.append((time.perf_counter() - t1) * 1e3)
+    eng.set_duration_read(False)
+    p50_pred = float(np.median(lat_pred[1:]))
 
     # ---- the gathered waveforms against the engine's own PCM fetch (N > 1 code path): rank 0's block of the last gather must be the
     # bytes stn_batch_fetch_pcm16 returns for the same resident batch, and every rank's block must have arrived with its shape ---------
@@ -421,6 +434,9 @@ def main():
                        "hip_built": rt_info["hip_built"], "hip_runtime": rt_info["hip_runtime"], "torch_in_process": bool(rt_info["torch_preloaded"]),
                        "parallelism": f"utterance-sharded x{world}, RCCL gather of int16 PCM to rank 0 overlapped with the next step" if world > 1 else "single GPU"},
             "p50_latency_ms": round(p50, 3),
+            "lone_batch_predicted_path": {"p50_ms": round(p50_pred, 3),
+                                          "note": "one batch alone with the duration predictor, the device->host read of its durations and the wait for it on the critical "
+                                                  "path, as when durations are predicted (the other figures run with durations known on the host: no read); shapes forced"},
             "latency_note": "per-utterance latency = completion time of its 128-utterance batch (submit -> waveform in HBM), graph replay",
             "graph_replays_in_timed_region": replays_timed,
             "roofline": roof,

@@ -127,20 +127,31 @@ int stn_set_vocoder_mode(stn_handle* h, int length_aware);
  * latent frames each utterance owns (sum of lengths rows), 0 = padded [b*L + t] rows with the padding masked to zero after
  * every block.  The masked stages are row-independent, so both give the same latent; packed does no work on padding. */
 int stn_set_row_layout(stn_handle* h, int packed);
+/* Shape buckets for the graph cache (default off).  A captured pipeline has every size baked in: B, Lt, L and the packed row counts.
+ * With buckets on, Lt, L and the row counts are rounded UP to bucket boundaries (4-8 per octave, at most 25 % padding), so requests of
+ * unlike lengths that fall into the same buckets replay ONE captured graph instead of capturing one each — the case of a service
+ * that merges requests (/root/reference/py/service.py:79-136) and of the call() chunk loop (/root/reference/cpp/helper.cpp:697-719).
+ * The utterances' own lengths stay exact: every utterance's frames and samples are bit-identical to the unbucketed run.  What the
+ * caller sees: stn_batch_dims reports the bucketed L (W = L * chunk samples) and fetched rows have that length (zeros / the dense
+ * vocoder's padding response behind an utterance's own samples, as before); B stays exact; injected noise keeps L exact. */
+int stn_set_shape_buckets(stn_handle* h, int on);
+/* Measurement aid.  stn_batch_upload with a duration override skips the one device->host read of a synthesis (the predicted
+ * durations, which size every later buffer): with always != 0 the read and the wait for it are performed anyway, so a timed run has
+ * the critical path of a predicted-duration run (duration predictor -> read -> rest) on the controlled shapes of a forced one. */
+int stn_set_duration_read(stn_handle* h, int always);
 /* GELU form of the loaded model: 0 = erf (default), 1 = the tanh approximation 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3))).
  * stn_load_dir sets it from how the graphs spell the activation (Gelu / Erf: 0; Tanh inside the GELU pattern or Gelu approximate="tanh":
  * 1); a synthetic-weight engine that should compute the tanh form sets it here.  fp32 and f16 engines follow it exactly (the fused K4
  * kernels of the 16-bit modes compute the exp2 = tanh form either way, bf16 stores the tanh-form shortcut: DESIGN.md 5d). */
 int stn_set_gelu_form(stn_handle* h, int tanh_form);
 int stn_get_gelu_form(const stn_handle* h);
-/* Cross-attention blocks of the vector estimator: 3 (default) = head-split: fold_ln (or LayerNorm) + ONE launch per block that
+/* Cross-attention blocks of the vector estimator: non-zero (default) = head-split: fold_ln (or LayerNorm) + ONE launch per block that
  * computes, per (utterance pair, head), the q projection, its rotation, the attention and the head's share of the output projection
  * and leaves it as a 16-bit per-head partial sum which the next ConvNeXt block's fold adds to the residual stream in head order
  * (kernels_xattn_hs.hip; 16-bit modes, packed rows with K4-split active, <= 256 frames per utterance, contexts of <= 128 keys: other
- * shapes take the four launches); 0 = four launches (LayerNorm, q projection, attention, output projection + residual); 1 = one fused
- * launch per utterance tile, 2 = the same cut in two behind the q projection (kernels_xattn.hip; measured at parity / slower).  Same
- * result up to the rounding of the 16-bit intermediates (3: and of the per-head partial sums); 1 and 2 give the same bits
- * (tests/test_gpu_xattn.py).  Other values: 0. */
+ * shapes take the four launches); 0 = four launches (LayerNorm, q projection, attention, output projection + residual).  Same result up
+ * to the rounding of the per-head partial sums (tests/test_gpu_xattn.py).  (Rounds 1-3 had per-utterance one- and two-launch forms
+ * here; they measured at parity or slower and were retired when the head-split form replaced them.) */
 int stn_set_fused_xattn(stn_handle* h, int on);
 /* K4 — the pointwise pair of a ConvNeXt block (pw1 -> GELU -> pw2 -> layer scale + residual) as ONE launch whose 4C-wide hidden
  * activation never leaves the registers (bf16 and f16 engines, block widths 384 / 512, batches of >= 18432 rows — below that a workgroup per 128 rows leaves most of the chip

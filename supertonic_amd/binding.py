@@ -121,6 +121,8 @@ def load():
     L.stn_set_vocoder_mode.argtypes = [vp, ci]
     L.stn_set_row_layout.argtypes = [vp, ci]
     L.stn_set_fused_xattn.argtypes = [vp, ci]
+    L.stn_set_shape_buckets.argtypes = [vp, ci]
+    L.stn_set_duration_read.argtypes = [vp, ci]
     L.stn_set_gelu_form.argtypes = [vp, ci]
     L.stn_get_gelu_form.argtypes = [vp]
     L.stn_batch_ve_rows.argtypes = [vp]
@@ -393,6 +395,14 @@ class Engine:
         """K4 stage mask: 1 vocoder, 2 vector estimator, 4 text encoder / duration predictor (0 = two GEMM launches everywhere)."""
         self._ck(self._lib.stn_set_fused_ffn(self._h, int(mask)))
 
+    def set_shape_buckets(self, on=True):
+        """Round Lt, L and the packed row counts up to bucket boundaries so that requests of unlike lengths share captured graphs."""
+        self._ck(self._lib.stn_set_shape_buckets(self._h, int(bool(on))))
+
+    def set_duration_read(self, always):
+        """Measurement aid: read the predicted durations back even when they are overridden (the critical path of a predicted-duration run)."""
+        self._ck(self._lib.stn_set_duration_read(self._h, int(bool(always))))
+
     def set_gelu_form(self, tanh_form):
         """0 erf (default), 1 the tanh approximation (what stn_load_dir selects for graphs that spell GELU with Tanh)."""
         self._ck(self._lib.stn_set_gelu_form(self._h, int(bool(tanh_form))))
@@ -402,8 +412,7 @@ class Engine:
         return self._lib.stn_get_gelu_form(self._h)
 
     def set_fused_xattn(self, on=True):
-        """Cross-attention blocks of the vector estimator: 3 head-split (default), 0 / False four launches, 1 / True one fused launch per
-        utterance tile, 2 the same in two launches."""
+        """Cross-attention blocks of the vector estimator: True head-split (default), False four launches."""
         self._ck(self._lib.stn_set_fused_xattn(self._h, int(on)))
 
     @property

@@ -277,6 +277,8 @@ int stn_set_graph_mode(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_graph_m
 int64_t stn_batch_vo_rows(const stn_handle* h) { return h ? h->eng->last_vo_rows() : 0; }
 int64_t stn_batch_ve_rows(const stn_handle* h) { return h ? h->eng->last_ve_rows() : 0; }
 int stn_set_row_layout(stn_handle* h, int packed) { STN_TRY(h, { h->eng->set_packed_rows(packed != 0); }) }
+int stn_set_shape_buckets(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_shape_buckets(on != 0); }) }
+int stn_set_duration_read(stn_handle* h, int always) { STN_TRY(h, { h->eng->set_duration_read(always != 0); }) }
 int stn_set_gelu_form(stn_handle* h, int tanh_form) { STN_TRY(h, { h->eng->set_gelu_form(tanh_form); }) }
 int stn_get_gelu_form(const stn_handle* h) { return h ? h->eng->gelu_form() : STN_ERR_INVALID; }
 int stn_set_fused_xattn(stn_handle* h, int on) { STN_TRY(h, { h->eng->set_fused_xattn(on); }) }

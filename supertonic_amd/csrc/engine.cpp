@@ -126,7 +126,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
     if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
     if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
-    if (const char* p = getenv("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks in one (1) or two (2) launches, or head-split (3)
+    if (const char* p = getenv("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks head-split (default) or as four launches (0)
     if (const char* p = getenv("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
     if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
@@ -842,9 +842,9 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
         // q from x, K/V precomputed (columns blk*2C .. of kv_all, row stride nb*2C)
         const Attn w = attn_w(p, false);
         const char* kp0 = static_cast<const char*>(kv_all) + (size_t)blk * 2 * C * esz;
-        const auto fq = frag_w_.find(w.q.w.as(dt_)), fo = frag_w_.find(w.o.w.as(dt_));
+        const auto fq = frag_w_.find(w.q.w.as(dt_));
         const auto foa = frag_acc_w_.find(w.o.w.as(dt_));
-        if (fused_xattn_ == 3 && fsp && unit_vec_ && C <= 1024 && fq != frag_w_.end() && foa != frag_acc_w_.end() && xattn_hs_supported(dt_, C, H, L, Lk, nb * 2 * C) &&
+        if (fused_xattn_ && fsp && unit_vec_ && C <= 1024 && fq != frag_w_.end() && foa != frag_acc_w_.end() && xattn_hs_supported(dt_, C, H, L, Lk, nb * 2 * C) &&
             M * C * 2 < 0x7FFFFFFFll) {
             // HEAD-SPLIT: fold_ln (or LayerNorm), then ONE launch per block — q projection, rotation, attention and the head's share of the
             // output projection per (utterance pair, head), stored as four 16-bit per-head partial sums in K4-split's layout; the next
@@ -865,34 +865,6 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
             fs.fold.part = fs.part; fs.fold.S = H; fs.fold.part_stride = fs.part_stride;
             fs.fold.b2 = w.o.b ? w.o.b : unit_vec_ + 1024; fs.fold.gamma = unit_vec_;  // x + 1 * (sum + bo): the product with 1 is exact
             ar_.release(m2);
-            return;
-        }
-        if ((fused_xattn_ == 1 || fused_xattn_ == 2) && fq != frag_w_.end() && fo != frag_w_.end() && xattn_fused_supported(dt_, C, H, Lk, nb * 2 * C)) {
-            // fold (when the previous block left one), LayerNorm, q projection, attention, output projection and the residual add in ONE launch
-            if (kv_all == c.text_kv && text_gate_) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }
-            if (fused_xattn_ == 2) {  // two launches, the q rows through a buffer
-                const Arena::Mark m2 = ar_.mark();
-                void* qb = act_alloc(M * C);
-                if (prof_on_) prof_begin("xattn_q", 2.0 * M * (double)C * C, (double)M * C * (8.0 + esz) + (double)C * C * esz);
-                launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
-                                   w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,
-                                   a.larope_gamma, fs.pending ? &fs.fold : nullptr, 1, qb);
-                if (prof_on_) prof_end();
-                if (prof_on_) prof_begin("xattn_o", 2.0 * M * (double)C * C + 4.0 * M * (double)Lk * C, (double)M * C * (8.0 + esz) + (double)C * C * esz + (double)B * Lk * 2 * C * esz);
-                launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
-                                   w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,
-                                   a.larope_gamma, nullptr, 2, qb);
-                if (prof_on_) prof_end();
-                ar_.release(m2);
-                fs.pending = false;
-                return;
-            }
-            if (prof_on_) prof_begin("xattn_fused", 4.0 * M * (double)C * C + 4.0 * M * (double)Lk * C, (double)M * C * 8.0 + 2.0 * C * C * esz + (double)B * Lk * 2 * C * esz);
-            launch_xattn_fused(s_, dt_, fs.x, w.ln.g, w.ln.b, a.ln_eps, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, fo->second,
-                               w.o.b, B, L, C, H, Lk, llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base,
-                               a.larope_gamma, fs.pending ? &fs.fold : nullptr);
-            if (prof_on_) prof_end();
-            fs.pending = false;
             return;
         }
         const Arena::Mark m2 = ar_.mark();
@@ -986,7 +958,7 @@ void Engine::prepare_xattn_weights() {
     frag_acc_w_.clear();
     const stn_arch& a = a_;
     unit_vec_ = nullptr;
-    if (!is_half(dt_) || !xattn_fused_supported(dt_, a.ve_dim, a.ve_heads, 1, 8)) return;
+    if (!is_half(dt_) || !xattn_hs_supported(dt_, a.ve_dim, a.ve_heads, 1, 1, 8)) return;
     {
         std::vector<float> uv(2048, 0.f);
         std::fill(uv.begin(), uv.begin() + 1024, 1.f);
@@ -999,12 +971,12 @@ void Engine::prepare_xattn_weights() {
     for (int blk = 0; blk < a.ve_main_blocks; ++blk)
         for (const char* kind : {".text", ".style"}) {
             const Attn w = attn_w("ve.m" + std::to_string(blk) + kind, false);
-            for (const Linear* lin : {&w.q, &w.o}) {
-                const void* src = lin->w.as(dt_);
+            {   // Wq in MFMA fragment order (a head's 96 rows are one contiguous 72 KiB)
+                const void* src = w.q.w.as(dt_);
                 void* dst = nullptr;
-                STN_HIP(hipMalloc(&dst, (size_t)lin->N * lin->K * 2));
+                STN_HIP(hipMalloc(&dst, (size_t)w.q.N * w.q.K * 2));
                 owned_.push_back(dst);
-                launch_repack_frag(s_, src, lin->N, lin->K, dst);
+                launch_repack_frag(s_, src, w.q.N, w.q.K, dst);
                 frag_w_[src] = dst;
             }
             {   // Wo once more in the k order of an accumulator used as the B operand (the head-split block's output projection)

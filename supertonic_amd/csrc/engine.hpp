@@ -114,7 +114,7 @@ class Engine {
     void vocoder_dev(int B, int L, const float* latent, float* wav, const int* vlen = nullptr, int vrows = 0,
                      const int* valid = nullptr);
     int vocoder_receptive_field() const;  // frames on either side that one output frame depends on
-    void prepare_xattn_weights();         // fragment-ordered copies of the estimator's cross-attention Wq / Wo (kernels_xattn.hip)
+    void prepare_xattn_weights();         // fragment-ordered copies of the estimator's cross-attention Wq / Wo (kernels_xattn_hs.hip)
     std::unordered_map<const void*, const void*> frag_w_;  // row-major 16-bit matrix -> its fragment-ordered copy
     // diagnostics: stamps of the head-split cross-attention launches (stn_dbg_xattn_hs_*)
     void hs_stamps_enable(bool on);
@@ -183,8 +183,26 @@ class Engine {
     // exp2 (= tanh) form in both 16-bit modes.
     void set_gelu_form(int tanh_form) { if ((tanh_form != 0) != (gelu_act_ == ACT_GELU_TANH)) { sync(); drop_graphs(); } gelu_act_ = tanh_form ? ACT_GELU_TANH : ACT_GELU; }
     int gelu_form() const { return gelu_act_ == ACT_GELU_TANH ? 1 : 0; }
-    // cross-attention blocks of the estimator as ONE launch each (kernels_xattn.hip) instead of four
-    void set_fused_xattn(int mode) { fused_xattn_ = mode < 0 || mode > 3 ? 0 : mode; }  // 0: four launches, 1: one, 2: two (cut behind the q projection), 3: head-split (fold_ln + one launch, kernels_xattn_hs.hip)
+    // Shape buckets for the graph cache (the service path: requests of unlike lengths).  A captured pipeline has every size baked in:
+    // B, Lt, L and the packed row counts (sum of the latent lengths, of the token counts, the vocoder's rows).  With buckets on, Lt, L and
+    // the three row counts are rounded UP to a bucket boundary (bucket_up: four buckets per octave, <= 25 % padding) — the utterances'
+    // own lengths stay exact and travel through device memory, so two requests that fall into the same buckets replay ONE graph.  Rows
+    // behind the last sequence are dead: the row-independent kernels compute garbage there that nothing reads, the per-sequence kernels
+    // never touch them, and every utterance's result over its own frames is bit-identical to the unbucketed run.  What changes for the
+    // caller: stn_batch_dims reports the bucketed L (and W = L * chunk samples) and the fetched rows are that long.  B stays exact.
+    // (No cached graph is dropped by the switch: a graph is fully described by the sizes in its key, bucketed or not.)
+    void set_shape_buckets(bool on) { shape_buckets_ = on; }
+    static int64_t bucket_up(int64_t x, int64_t min_gran) {
+        if (x <= 0) return x;
+        int64_t g = min_gran;
+        while (g * 8 <= x) g *= 2;  // granularity = a quarter .. an eighth of x, at least min_gran: 4 - 8 buckets per octave
+        return (x + g - 1) / g * g;
+    }
+    // measurement aid (bench.py `lone_batch_predicted_path`): with durations forced for shape control the predictor's device->host read
+    // is skipped; this switch performs the read and the wait anyway, so the timed critical path is that of a predicted-duration run
+    void set_duration_read(bool always) { dur_read_always_ = always; }
+    // cross-attention blocks of the estimator head-split (kernels_xattn_hs.hip) instead of four launches
+    void set_fused_xattn(int mode) { fused_xattn_ = mode ? 1 : 0; }  // 0: four launches; otherwise head-split (fold_ln + one launch, kernels_xattn_hs.hip)
     // K4: the pointwise pair of a ConvNeXt block as one launch.  Bit mask over the stages: 1 = vocoder, 2 = vector estimator,
     // 4 = text encoder / duration predictor.  bf16 engines, widths 256 / 384 / 512 (ffn_fused_supported)
     // 8 = the estimator's blocks as K4-split (hidden dimension cut over 4 workgroups per 128-row slab, 16-bit partial sums folded
@@ -366,9 +384,11 @@ class Engine {
     int64_t ffn_min_rows_ = 18432;  // K4 only from this many rows on (144 workgroups); STN_FFN_MIN_ROWS overrides
     int64_t ffn_split_min_rows_ = 1;     // K4-split from this many rows on (with the slab staged through LDS one utterance gains too: 20.0 vs 21.4 us per block); STN_FFN_SPLIT_MIN_ROWS overrides
     int fused_ffn_ = 9;         // K4 stages (set_fused_ffn): adopted where measured faster; STN_FFN=<mask> overrides
+    bool shape_buckets_ = false;
+    bool dur_read_always_ = false;  // measurement: read the predicted durations back (and wait for them) even when the caller overrides them
     int gelu_act_ = ACT_GELU;
-    int fused_xattn_ = 3;  // cross-attention blocks of the estimator: 3 head-split (fold_ln + one launch, kernels_xattn_hs.hip; the default), 0 four launches,
-                           // 1 one launch per utterance tile, 2 the same cut in two (kernels_xattn.hip); STN_XATTN=<0..3> overrides
+    int fused_xattn_ = 1;  // cross-attention blocks of the estimator: head-split (fold_ln + one launch, kernels_xattn_hs.hip; the default) or, 0, four
+                           // launches; STN_XATTN=<0|1> overrides
     int64_t last_ve_rows_ = 0, last_vo_rows_ = 0;
     float* vo_quiet_ = nullptr;  // [base_chunk_size]      } zero-latent response of the vocoder (device, owned), 16-bit engines
     float* vo_edge_ = nullptr;   // [rf][base_chunk_size]  }

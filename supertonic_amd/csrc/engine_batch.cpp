@@ -42,6 +42,8 @@ void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_m
     for (void* p : batch_retired_) (void)hipFree(p);
     batch_retired_.clear();
     Batch& b = bt_;
+    const int Lt_in = Lt;  // the caller's row stride of ids / text_mask
+    if (shape_buckets_) Lt = (int)bucket_up(Lt, 32);  // token rows padded with id 0 / mask 0: the lengths come from the mask, not from Lt
     b.B = B; b.Lt = Lt; b.L = 0; b.noise_L = 0; b.total_step = 0;
     b.have_override = false; b.have_noise = false;
     b.h_dur.clear(); b.h_llen.clear();
@@ -53,23 +55,29 @@ void Engine::batch_upload(int B, int Lt, const int64_t* ids, const float* text_m
     ensure(b.dur, b.dur_cap, (size_t)B);
     ensure(b.llen, b.llen_cap, (size_t)B);
     ensure(b.utt_ids, b.utt_cap, (size_t)B);
-    STN_HIP(hipMemcpyAsync(b.ids, ids, sizeof(int64_t) * B * Lt, hipMemcpyHostToDevice, s_));
+    if (Lt != Lt_in) {
+        STN_HIP(hipMemsetAsync(b.ids, 0, sizeof(int64_t) * B * Lt, s_));
+        STN_HIP(hipMemcpy2DAsync(b.ids, sizeof(int64_t) * Lt, ids, sizeof(int64_t) * Lt_in, sizeof(int64_t) * Lt_in, (size_t)B, hipMemcpyHostToDevice, s_));
+    } else {
+        STN_HIP(hipMemcpyAsync(b.ids, ids, sizeof(int64_t) * B * Lt, hipMemcpyHostToDevice, s_));
+    }
     STN_HIP(hipMemcpyAsync(b.style_ttl, style_ttl, sizeof(float) * n_ttl, hipMemcpyHostToDevice, s_));
     STN_HIP(hipMemcpyAsync(b.style_dp, style_dp, sizeof(float) * n_dp, hipMemcpyHostToDevice, s_));
     std::vector<int64_t> uid(B);
     for (int i = 0; i < B; ++i) uid[i] = utt_ids ? utt_ids[i] : i;
     STN_HIP(hipMemcpyAsync(b.utt_ids, uid.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s_));
     ar_.reset();
-    float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt);
-    launch_mask_to_len(s_, d_mask, B, Lt, b.tlen);
+    float* d_mask = up(ar_, s_, text_mask, (size_t)B * Lt_in);
+    launch_mask_to_len(s_, d_mask, B, Lt_in, b.tlen);
     // packed text rows: first row of each utterance (fixed for the life of this upload) and their total
     ensure(b.toff, b.toff_cap, (size_t)B + 1);
     b.trows = 0;
     for (int i = 0; i < B; ++i) {
         int n = 0;
-        for (int t = 0; t < Lt; ++t) n += text_mask[(size_t)i * Lt + t] > 0.5f ? 1 : 0;  // as mask_to_len_kernel counts
+        for (int t = 0; t < Lt_in; ++t) n += text_mask[(size_t)i * Lt_in + t] > 0.5f ? 1 : 0;  // as mask_to_len_kernel counts
         b.trows += n;
     }
+    if (shape_buckets_) b.trows = (int)bucket_up(b.trows, 64);  // dead text rows behind the last utterance (toff[B] keeps the exact sum)
     if (B <= 1024) launch_row_map(s_, b.tlen, B, b.toff, nullptr);
     b.have_override = duration_override != nullptr;
     if (duration_override) b.h_dur.assign(duration_override, duration_override + B);
@@ -140,13 +148,14 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
         {   // 1. duration predictor (always executed; its output may be overridden for shape control), beside the encoder
             Side side(*this, dp_s_, dp_ar_);
             duration_dev(B, Lt, b.ids, b.style_dp, b.tlen, b.dur, tpk ? &trg : nullptr);
-            if (!b.have_override) {
+            if (!b.have_override || dur_read_always_) {
                 STN_HIP(hipMemcpyAsync(dur.data(), b.dur, sizeof(float) * B, hipMemcpyDeviceToHost, s_));
                 STN_HIP(hipEventRecord(ev_dp_, s_));
             }
         }
-        if (b.have_override) dur = b.h_dur;  // known on the host: no device->host read, no sync
-        else STN_HIP(hipEventSynchronize(ev_dp_));  // the one host round trip (the predictor only): L = f(max duration) sizes every later buffer
+        if (!b.have_override || dur_read_always_) STN_HIP(hipEventSynchronize(ev_dp_));  // the one host round trip (the predictor only): L = f(max duration) sizes every later buffer
+        if (b.have_override) dur = b.h_dur;  // known on the host: no device->host read, no sync (unless the measurement switch asks for the read: the
+                                             // critical path of a predicted-duration run on the controlled shapes of a forced one)
     }
     // Hand-over of this run's text rows to the main pipeline (everything captured below reads b.text_rows).  It happens where the
     // rows are first needed — in front of the text K/V GEMM of the first text cross-attention — so the noise, the style K/V, the time
@@ -162,6 +171,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     int L = 0;
     latent_geometry(a, dur, L, b.h_llen);
     if (L < 1) throw std::runtime_error("predicted duration too short: zero latent frames");
+    if (shape_buckets_ && !b.have_noise) L = (int)bucket_up(L, 16);  // (injected noise has the caller's exact [B, D, L] layout)
     if (b.have_noise && b.noise_L != L)
         throw std::runtime_error("injected noise has L=" + std::to_string(b.noise_L) + " but the durations imply L=" + std::to_string(L));
     b.L = L;
@@ -199,11 +209,18 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
     key.ffn = fused_ffn_; key.gen = b.gen; key.wgen = wgen_; key.pin = pin_llen_;
     key.rows = 0;
     if (packed_rows_ok(B)) for (int v : b.h_llen) key.rows += v;
+    if (shape_buckets_) key.rows = (int)bucket_up(key.rows, 64);
     last_ve_rows_ = key.rows ? key.rows : (int64_t)B * L;
     key.vrows = trimmed_rows(B, L, nullptr);
+    if (shape_buckets_) key.vrows = (int)bucket_up(key.vrows, 64 * a.chunk_compress_factor);
     key.trows = tpk ? b.trows : 0;
     last_vo_rows_ = (int64_t)B * L * a.chunk_compress_factor;
-    if (vo_ragged_ && packed_ve_ && is_half(dt_)) { last_vo_rows_ = 0; for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor; }
+    if (vo_ragged_ && packed_ve_ && is_half(dt_)) {
+        last_vo_rows_ = 0;
+        for (int v : b.h_llen) last_vo_rows_ += (int64_t)v * a.chunk_compress_factor;
+        if (shape_buckets_) last_vo_rows_ = bucket_up(last_vo_rows_, 64 * a.chunk_compress_factor);
+        key.vrows = (int)last_vo_rows_;  // (the length-aware vocoder's packed rows are baked into the pipeline like the others)
+    }
     else if (key.vrows) last_vo_rows_ = key.vrows;
     key.p0 = b.xt[0]; key.p1 = b.wav; key.s = s_;
     // event timing forces eager launches: hipEventRecord captured into a graph returns garbage spans on ROCm 7.2 (measured)
@@ -317,9 +334,10 @@ void Engine::enqueue_after_duration(int total_step, const std::function<void()>&
     if (packed_rows_ok(B)) {  // the estimator works on the frames the utterances own and nothing else
         rg.rows = 0;
         for (int v : b.h_llen) rg.rows += v;
+        if (shape_buckets_) rg.rows = (int)bucket_up(rg.rows, 64);  // dead rows behind the last utterance (as in the graph key)
         int* off = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)(B + 1)));
         int* row_b = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)std::max(rg.rows, 1)));
-        launch_row_map(s_, b.llen, B, off, row_b);
+        launch_row_map(s_, b.llen, B, off, row_b, rg.rows);
         rg.off = off; rg.row_b = row_b;
         rgp = &rg;
     }
@@ -341,7 +359,9 @@ void Engine::enqueue_after_duration(int total_step, const std::function<void()>&
     const int* valid = nullptr;
     if (vo_ragged_ && packed_ve_) {
         for (int v : b.h_llen) vrows += v * a.chunk_compress_factor;
-    } else if (const int tr = trimmed_rows(B, L, nullptr)) {
+        if (shape_buckets_) vrows = (int)bucket_up(vrows, 64 * a.chunk_compress_factor);
+    } else if (int tr = trimmed_rows(B, L, nullptr)) {
+        if (shape_buckets_) tr = (int)bucket_up(tr, 64 * a.chunk_compress_factor);
         // reference (dense) semantics at the cost of the frames that are not position-independent
         int* n_dev = static_cast<int*>(ar_.alloc(sizeof(int) * B));
         int* v_dev = static_cast<int*>(ar_.alloc(sizeof(int) * B));

@@ -95,9 +95,10 @@ TextToSpeech::SynthesisResult TextToSpeech::call(const std::string& text, const 
         ModeGuard(stn_handle* h0, stn_group* grp) {
             if (grp) for (int r = 0; r < stn_group_size(grp); ++r) hs.push_back(stn_group_handle(grp, r));
             else hs.push_back(h0);
-            for (stn_handle* h : hs) check(h, stn_set_vocoder_mode(h, 1));
+            for (stn_handle* h : hs) { check(h, stn_set_vocoder_mode(h, 1)); check(h, stn_set_shape_buckets(h, 1)); }  // chunk batches of any
+                                                                                                                      // length share captured graphs
         }
-        ~ModeGuard() { for (stn_handle* h : hs) (void)stn_set_vocoder_mode(h, 0); }
+        ~ModeGuard() { for (stn_handle* h : hs) { (void)stn_set_vocoder_mode(h, 0); (void)stn_set_shape_buckets(h, 0); } }
     } guard(h_, grp_);
     const SynthesisResult r = infer(chunks, std::vector<std::string>((size_t)n, lang), rep, total_step, speed);
     const size_t W = r.wav.size() / (size_t)n;

@@ -184,7 +184,8 @@ void launch_dwconv_ln(hipStream_t s, int out_dtype, const float* x, int B, int L
 // Packed ("ragged") rows: sequence b owns rows row_off[b] .. row_off[b] + len[b] of x / y and nothing else — no padding rows
 // exist.  row_off has B+1 entries (launch_row_map); supported where dwconv_ln_supports_packed(C, k).
 bool dwconv_ln_supports_packed(int C, int k);
-void launch_row_map(hipStream_t s, const int* len, int B, int* row_off /*[B+1]*/, int* row_b /*[sum len] or null*/);
+void launch_row_map(hipStream_t s, const int* len, int B, int* row_off /*[B+1]*/, int* row_b /*[sum len] or null*/,
+                    int rows_padded = 0 /* row_b has this many entries: those behind sum len are set to sequence 0 (shape buckets) */);
 // plain LayerNorm over C: x fp32 -> y act
 void launch_layernorm(hipStream_t s, int out_dtype, const float* x, int64_t M, int C, const float* g, const float* b,
                       float eps, void* y);
@@ -198,21 +199,9 @@ void launch_attention(hipStream_t s, int dtype, const void* q, int ldq, const vo
                       float rope_base, float rope_gamma, bool k_rotated = false,
                       const int* q_off = nullptr /* packed query/output rows: sequence b starts at q_off[b], owns qlen[b] */,
                       const int* k_off = nullptr /* packed key/value rows: sequence b starts at k_off[b], owns klen[b] */);
-// One launch for a whole cross-attention block on rows of the residual stream (kernels_xattn.hip):
-//   x <- x + Wo . attention(Wq . LN(x) + bq, K, V) + bo, keys/values given (already projected, keys already rotated when rope_mode >= 0).
-// Supported where xattn_fused_supported() says so (16-bit modes, the vector estimator's width, contexts of <= 128 keys).
-// fold (optional): a pending K4-split update of x, folded in front of the LayerNorm (x is updated in place either way).
-bool xattn_fused_supported(int dtype, int C, int H, int Lk, int ldk);
-// Wq / Wo of launch_xattn_fused are passed in MFMA fragment order: [N][K] row-major 16-bit -> launch_repack_frag (once, at model load)
 // [N][K] row-major 16-bit -> MFMA fragment order (one contiguous KiB per operand; kernels_ffn.hip), once at model load
 void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf);
-struct FoldArgs;
-void launch_xattn_fused(hipStream_t s, int dtype, float* x, const float* ln_g, const float* ln_b, float eps, const void* Wq, const float* bq,
-                        const void* kp, const void* vp, int ldk, const void* Wo, const float* bo, int B, int L, int C, int H, int Lk,
-                        const int* qlen, const int* klen, const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma,
-                        const FoldArgs* fold = nullptr, int part = 0 /* 0: one launch; 1 / 2: the two halves, q rows through qbuf */,
-                        void* qbuf = nullptr);
-// The same block HEAD-SPLIT (kernels_xattn_hs.hip): one launch computes, per head h, q_h = Wq_h . xn + bq_h, its rotation, the attention
+// One launch per cross-attention block of the vector estimator, HEAD-SPLIT (kernels_xattn_hs.hip): one launch computes, per head h, q_h = Wq_h . xn + bq_h, its rotation, the attention
 // over the given K / V and the head's share of the output projection, and stores it as a 16-bit partial sum part[h][row][:] in K4-split's
 // layout; x <- x + ((p0 + p1) + p2) + p3 + bo is applied by the next reader of x through FoldArgs{part, S = 4, b2 = bo} (launch_fold_dwconv_ln
 // / launch_fold_ln).  xn = LayerNorm(x) rows (16-bit, [M][C]); WqF = launch_repack_frag(Wq), WoA = launch_repack_frag_acc(Wo), both [C][C];

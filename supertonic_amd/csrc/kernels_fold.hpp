@@ -1,4 +1,4 @@
-// kernels_fold.hpp — device helpers of the K4-split fold (kernels_misc.hip: fold_ln / fold_dwconv_ln; kernels_xattn.hip): ONE
+// kernels_fold.hpp — device helpers of the K4-split fold (kernels_misc.hip: fold_ln / fold_dwconv_ln; kernels_xattn_hs.hip feeds the same fold): ONE
 // definition of the summation order, so that every reader of a pending update computes the same bits.
 //   x_new = x + gamma * ((((p0 + p1) + p2) + ... + p_{S-1}) + b2) + rowvec[seq]          (fp32)
 #pragma once

@@ -835,7 +835,7 @@ void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const fl
 }
 
 // row_off[b] = sum of len[0..b) (row_off[B] = total), row_b[row_off[b] + t] = b: the packed-row bookkeeping, one block
-__global__ void row_map_kernel(const int* __restrict__ len, int B, int* __restrict__ row_off, int* __restrict__ row_b) {
+__global__ void row_map_kernel(const int* __restrict__ len, int B, int* __restrict__ row_off, int* __restrict__ row_b, int rows_padded) {
     __shared__ int off_s[1025];
     if (threadIdx.x == 0) {
         int a = 0;
@@ -849,6 +849,8 @@ __global__ void row_map_kernel(const int* __restrict__ len, int B, int* __restri
         const int o = off_s[b], n = off_s[b + 1] - o;
         for (int t = threadIdx.x; t < n; t += blockDim.x) row_b[o + t] = b;
     }
+    // dead rows behind the last sequence (a row count rounded up to a shape bucket): sequence 0, so that per-row lookups stay in range
+    for (int t = off_s[B] + threadIdx.x; t < rows_padded; t += blockDim.x) row_b[t] = 0;
 }
 
 // packed rows [sum len][W] -> padded [B][T][W] with zeros past each sequence's length (W % 4 == 0)
@@ -870,10 +872,10 @@ void launch_unpack_rows(hipStream_t s, const float* src, const int* len, const i
     if (W % 4) { throw std::invalid_argument("unpack_rows needs W % 4 == 0"); }
     STN_KLAUNCH(unpack_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, len, row_off, T, W / 4, n4, dst);
 }
-void launch_row_map(hipStream_t s, const int* len, int B, int* row_off, int* row_b) {
+void launch_row_map(hipStream_t s, const int* len, int B, int* row_off, int* row_b, int rows_padded) {
     if (B <= 0) return;
     if (B > 1024) { throw std::invalid_argument("packed layout supports at most 1024 sequences per batch"); }
-    STN_KLAUNCH(row_map_kernel, dim3(1), dim3(1024), 0, s, len, B, row_off, row_b);
+    STN_KLAUNCH(row_map_kernel, dim3(1), dim3(1024), 0, s, len, B, row_off, row_b, rows_padded);
 }
 
 template <typename OutT>

@@ -76,11 +76,16 @@ class TextToSpeech:
             raise ValueError("Number of texts must match number of style vectors")
         ids, mask = self.text_processor(text_list, lang_list)
         with self._lock:
+            # length-aware batches (the chunks of a long text, the service's merged requests) come in ever-changing lengths: shape
+            # buckets let them share captured graphs (stn_set_shape_buckets: every row stays exact over its own samples, rows are
+            # just longer); a plain batch keeps the reference's exact [B, L * chunk] result
             self.engine.set_vocoder_mode(length_aware)
+            self.engine.set_shape_buckets(length_aware)
             try:
                 return self.engine.synthesize(ids, mask, style.ttl, style.dp, total_step, speed, noise_seed=self._seed())
             finally:
                 self.engine.set_vocoder_mode(False)
+                self.engine.set_shape_buckets(False)
 
     def latent_lengths(self, durations):
         """Latent frames each utterance occupies (get_latent_mask, py/helper.py:276-282) from its returned duration."""

@@ -31,6 +31,8 @@ def test_bench_json_line_contract():
     assert d["config"]["torch_in_process"] is False and d["config"]["hip_runtime"] // 100000 == d["config"]["hip_built"] // 100000, d["config"]
     assert "was built against HIP" not in p.stderr, p.stderr[-1500:]
     assert d["warmup_run"] >= 3
+    # a lone batch on the critical path of a predicted-duration run (predictor -> host read -> rest) costs at least the forced-duration one
+    assert d["lone_batch_predicted_path"]["p50_ms"] >= 0.97 * d["p50_latency_ms"]
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1000 and abs(d["value"] - d["config"]["audio_sec_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     r = d["roofline"]

@@ -101,3 +101,50 @@ def test_batch_size_sequence_4_5_4():
         w, _ = eng.synthesize(*i[:4], 2, 1.0, duration_override=i[4], noise_seed=9)
         np.testing.assert_array_equal(w, want, err_msg=k)
     assert eng.graph_replays >= 6
+
+
+def test_shape_buckets_let_unlike_requests_share_a_graph():
+    """stn_set_shape_buckets: two length-aware requests of different lengths that fall into the same buckets replay ONE captured graph
+    (replays rise, cached graphs do not), and every utterance's frames and samples are bit-identical to the unbucketed run — the rows
+    are merely longer.  (the call() chunk loop /root/reference/cpp/helper.cpp:697-719, the service
+    /root/reference/py/service.py:79-136.)"""
+    from supertonic_amd import host, workload
+    from supertonic_amd.arch import default_arch
+    a = default_arch()
+    up = host.UnicodeProcessor(host.synthetic_indexer())
+
+    def request(seed, words):
+        texts = workload.utterances(6, min_words=words[0], max_words=words[1], seed=seed)
+        ids, mask = up(texts, ["en"] * 6)
+        sttl, sdp = workload.synthetic_styles(a, list(range(6)))
+        return ids, mask, sttl, sdp, workload.forced_durations(texts)
+
+    reqs = [request(s, (7, 9)) for s in (1, 2, 3, 4, 5, 6)]
+    eng = binding.Engine(0, "bf16")
+    eng.load_synthetic(a, 7)
+    eng.set_vocoder_mode(True)
+    exact = []
+    for ids, mask, sttl, sdp, durs in reqs:  # the unbucketed results (each request its own shapes: eager or its own graph)
+        wav, dur = eng.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=durs, noise_seed=4)
+        exact.append((wav.copy(), dur.copy(), eng.batch_fetch_latent().copy()))
+    eng.set_shape_buckets(True)
+    keys = set()
+    for rnd in range(3):  # first pass: eager (warm), second: capture, third: replay
+        c0, r0 = eng.graphs_cached, eng.graph_replays
+        for (ids, mask, sttl, sdp, durs), (wav0, dur0, lat0) in zip(reqs, exact):
+            wav, dur = eng.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=durs, noise_seed=4)
+            B, L, W = eng.batch_dims()
+            keys.add((L, eng.ve_rows))
+            lat = eng.batch_fetch_latent()
+            assert np.array_equal(dur, dur0) and W >= wav0.shape[1] and L >= lat0.shape[2]
+            ns = np.floor(dur * a.sample_rate).astype(int)
+            for b in range(6):
+                assert np.array_equal(wav[b, :ns[b]], wav0[b, :ns[b]]), (rnd, b)          # its own samples: the same bits
+            assert np.array_equal(lat[:, :, :lat0.shape[2]], lat0) and np.all(lat[:, :, lat0.shape[2]:] == 0)
+        if rnd == 2:
+            assert eng.graph_replays - r0 == len(reqs) and eng.graphs_cached == c0  # all six replayed, nothing new captured
+    # six requests of six different length profiles: fewer bucket combinations than requests, and at most that many graphs
+    n_exact = len({(r[0].shape[1], e[2].shape[2], int(sum(np.ceil(np.floor(e[1] * a.sample_rate) / a.chunk_size)))) for r, e in zip(reqs, exact)})
+    assert len(keys) < n_exact and eng.graphs_cached <= len(keys), (keys, n_exact, eng.graphs_cached)
+    print(f"shape buckets: {n_exact} exact shapes -> {len(keys)} bucketed shapes, {eng.graphs_cached} graphs cached")
+    eng.close()

@@ -104,3 +104,26 @@ def test_missing_assets_fail_at_startup_by_default(monkeypatch):
     monkeypatch.delenv("TTS_ALLOW_SYNTHETIC", raising=False)
     with pytest.raises(binding.StnError):
         tts_mod.load_text_to_speech("no_assets_here", use_gpu=True, dtype="bf16")
+
+
+def test_a_mixed_stream_of_requests_shares_a_few_captured_graphs(tts):
+    """Twenty single-speaker requests of 6..14 words, one after another (each its own length-aware batch of one through solo_batch, the
+    service's building block): with shape buckets the engine captures a handful of graphs for all of them instead of one per request
+    shape, and replays from then on.  (/root/reference/py/service.py:79-136 runs every request through its own _infer.)"""
+    from supertonic_amd import workload
+    st = _style(tts, ["F1"])
+    texts = workload.utterances(20, min_words=6, max_words=14, seed=77)
+    eng = tts.engine
+    shapes = set()
+    for rnd in range(3):
+        c0, r0 = eng.graphs_cached, eng.graph_replays
+        for t in texts:
+            waves, dur = tts.solo_batch([t], ["en"], st, 3, 1.05)
+            assert len(waves) == 1 and np.all(np.isfinite(waves[0])) and waves[0].size > 1000
+            B, L, W = eng.batch_dims()
+            shapes.add((L, eng.ve_rows))
+        if rnd == 2:
+            assert eng.graph_replays - r0 == len(texts) and eng.graphs_cached == c0  # steady state: every request replays
+    n_tokens = len({len(t) for t in texts})
+    print(f"20 requests, {n_tokens} distinct text lengths -> {len(shapes)} (L, rows) buckets, {eng.graphs_cached} graphs cached")
+    assert eng.graphs_cached <= 4 and n_tokens >= 10, (eng.graphs_cached, shapes)

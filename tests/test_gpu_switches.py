@@ -51,8 +51,7 @@ SWITCHES = [
     ("STN_FFN_SPLIT_MIN_ROWS", "100000", "bound"),
     ("STN_FFN_MIN_ROWS", "1", "bound"),    # vocoder K4 at every size
     ("STN_GEMM_TR", "0", "bound"),
-    ("STN_XATTN", "1", "bound"),           # the one-launch cross-attention block (opt-in)
-    ("STN_XATTN", "2", "bound"),           # ... as two launches
+    ("STN_XATTN", "0", "bound"),           # the cross-attention blocks as four launches instead of head-split
     ("STN_FOLD_TCH", "8", "equal"),        # the fold kernel's run length: the same bits either way
     ("STN_FOLD_TCH", "32", "equal"),
     ("STN_DWCONV_XCD", "0", "equal"),      # tile order of the comb kernel: placement only

@@ -13,7 +13,7 @@ ids, mask = host.UnicodeProcessor(host.synthetic_indexer())(texts, ["en"] * n)
 sttl, sdp = workload.synthetic_styles(a, np.arange(n))
 eng = binding.Engine(0, "bf16")
 eng.load_synthetic(a, 7)
-eng.set_fused_xattn(3)
+eng.set_fused_xattn(1)
 eng.set_graph_mode(False)
 eng.xattn_hs_stamps_enable(True)
 eng.batch_upload(ids, mask, sttl, sdp, duration_override=workload.forced_durations(texts), utt_ids=np.arange(n))
