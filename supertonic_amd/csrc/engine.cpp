@@ -858,7 +858,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
             unsigned long long* ts = nullptr;
             if (hs_ts_ && (int64_t)(B + 8) * H <= HS_TS_WG) { ts = hs_ts_; hs_ts_wgs_ = (B + 8) * H; }  // (an upper bound of the grid)
             launch_xattn_hs(s_, dt_, xn, M, fq->second, w.q.b, kp0, kp0 + (size_t)C * esz, nb * 2 * C, foa->second, fs.part, fs.part_stride, B, L, Lk,
-                            llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base, a.larope_gamma, ts);
+                            llen, klen, roff, kv_all == c.text_kv ? c.text_off : nullptr, rope_mode, a.rope_base, a.larope_gamma, ts, rg->hs_pairs);
             if (prof_on_) prof_end();
             fs.pending = true;
             fs.fold = FoldArgs{};

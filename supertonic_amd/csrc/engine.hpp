@@ -103,7 +103,8 @@ class Engine {
     // tb: rows of this step's time conditioning ([B][main_blocks*C]); nullptr -> computed here from the step counters
     // Packed ("ragged") latent rows: utterance b owns rows off[b] .. off[b] + llen[b] and no padding rows exist; `rows` is
     // their total.  The masked stages are row-independent, so this is an exact optimisation of the padded [b*L + t] layout.
-    struct Ragged { const int* off = nullptr; const int* row_b = nullptr; int rows = 0; };
+    struct Ragged { const int* off = nullptr; const int* row_b = nullptr; int rows = 0;
+                    const int* hs_pairs = nullptr; };  // (latent rows) which two utterances share a workgroup of the head-split cross-attention
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                      const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr,
                      const Ragged* rg = nullptr, const float* dt = nullptr /* 1/total_step per utterance, if precomputed */);

@@ -339,6 +339,11 @@ void Engine::enqueue_after_duration(int total_step, const std::function<void()>&
         int* row_b = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)std::max(rg.rows, 1)));
         launch_row_map(s_, b.llen, B, off, row_b, rg.rows);
         rg.off = off; rg.row_b = row_b;
+        if (fused_xattn_ && is_half(dt_) && B >= 2) {  // the head-split cross-attention's pairing, once per synthesis (the lengths are the run's)
+            int* pairs = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)(B + 2)));
+            launch_xattn_hs_pairs(s_, b.llen, B, pairs);
+            rg.hs_pairs = pairs;
+        }
         rgp = &rg;
     }
     int cur = 0;

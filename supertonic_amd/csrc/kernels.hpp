@@ -209,7 +209,12 @@ void launch_repack_frag(hipStream_t s, const void* W, int N, int K, void* Wf);
 bool xattn_hs_supported(int dtype, int C, int H, int L, int Lk, int ldk);
 void launch_xattn_hs(hipStream_t s, int dtype, const void* xn, int64_t M, const void* WqF, const float* bq, const void* kp, const void* vp, int ldk,
                      const void* WoA, void* part, int64_t part_stride, int B, int L, int Lk, const int* qlen, const int* klen,
-                     const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma, unsigned long long* ts = nullptr);
+                     const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma, unsigned long long* ts = nullptr,
+                     const int* pairs = nullptr /* launch_xattn_hs_pairs' table: which two utterances share a workgroup (null: 2g, 2g + 1) */);
+// utterances per workgroup a launch of this shape takes (1 or 2), and the pairing for 2: sorted by length, longest with shortest, so that
+// the pairs' row-tile counts are as equal as the batch allows (pairs: 2 * ceil(B / 2) ints; once per synthesis, the lengths do not change)
+int xattn_hs_group(int B, int L, int Lk);
+void launch_xattn_hs_pairs(hipStream_t s, const int* qlen, int B, int* pairs);
 // in-place RoPE of `groups` key blocks per row: element (row b*L+t, column g*group_stride + h*dh + i) for t < len[b]
 // (len null: all rows).  Keys that are reused by many attention launches (the vector estimator's text keys: every
 // block of every Euler step) are rotated once here instead of at every launch.  Same arithmetic as the attention

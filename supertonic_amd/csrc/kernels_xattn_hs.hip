@@ -98,6 +98,7 @@ struct HsArgs {
     uint16_t* part; int64_t part_stride; int64_t M;
     int ldk, B, G, Gpad, Lk, kc;
     const int* qlen; const int* klen; const int* q_off; const int* k_off;
+    const int* pairs;  // U = 2: the two utterances of group g are pairs[2g], pairs[2g+1] (-1: none); null: 2g and 2g + 1
     int rope_mode; float log_base, gamma;
     unsigned long long* ts;  // diagnostics: 8 shader-clock stamps per workgroup
 };
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
     int64_t row0[U], krow0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int b = g * U + u;
-        const bool ok = b < p.B;
+        const int b = (U > 1 && p.pairs) ? p.pairs[2 * g + u] : g * U + u;
+        const bool ok = b >= 0 && b < p.B;
         const int bb = ok ? b : 0;
         nq[u] = ok ? p.qlen[bb] : 0;
         nk[u] = ok ? (p.klen ? min(p.klen[bb], p.Lk) : p.Lk) : 0;
@@ -127,7 +128,12 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
         krow0[u] = p.k_off ? (int64_t)p.k_off[bb] : (int64_t)bb * p.Lk;
         ntl[u] = (nq[u] + 31) >> 5;
     }
-    const int T = ntl[0] + (U > 1 ? ntl[U - 1] : 0);
+    // The rows of the group's utterances, slot 0's then slot 1's, are ONE virtual sequence of N rows cut into 32-row tiles: a pair of
+    // 70 + 50 frames is 4 tiles, not 3 + 2, and with the pairs chosen longest-with-shortest (launch_xattn_hs_pairs) every workgroup of a
+    // batch of like lengths gets the same number — the launch is as long as its slowest workgroup.  A tile that straddles the two
+    // utterances runs the attention against both contexts and keeps, per lane, its own.
+    const int nq0 = nq[0], N = nq0 + (U > 1 ? nq[U - 1] : 0);
+    const int T = (N + 31) >> 5;
     if (T == 0) return;  // uniform
     unsigned long long t0 = 0;
     if (p.ts) t0 = __builtin_readcyclecounter();
@@ -139,18 +145,16 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
     unsigned char* const IMG = lds + HS_WB + wave * (32 * HS_IS);   // the wave's output image (output projection)
 
     // this wave's tiles
-    bool tv[2]; int tu[2], trow[2], tnv[2]; int64_t tg0[2];
+    bool tv[2]; int trow[2];  // tile e of this wave: virtual rows trow[e] .. trow[e] + 31
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int ti = wave + 4 * e;
         tv[e] = ti < T;
-        tu[e] = (U > 1 && ti >= ntl[0]) ? 1 : 0;
-        const int tl = ti - (tu[e] ? ntl[0] : 0);
-        trow[e] = tl * 32;
-        const int nqu = tu[e] ? nq[U - 1] : nq[0];
-        tnv[e] = tv[e] ? min(32, nqu - trow[e]) : 0;
-        tg0[e] = (tu[e] ? row0[U - 1] : row0[0]) + trow[e];
+        trow[e] = ti * 32;
     }
+    (void)ntl;
+    // virtual row -> global row of xn / part (beyond N: none)
+    auto grow_of = [&](int v) __attribute__((always_inline)) -> int64_t { return v < nq0 ? row0[0] + v : row0[U - 1] + (v - nq0); };
 
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.xn, (size_t)p.M * C * 2);
     const __amdgpu_buffer_rsrc_t rs_wq = make_rsrc(reinterpret_cast<const unsigned char*>(p.wq) + (size_t)h * HS_WB, HS_WB);
@@ -163,17 +167,17 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
     u32x4 ww[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) ww[i] = ldb128(rs_wq, (unsigned)(tid + 256 * i) * 16u);
-    auto issue_x = [&](int64_t grow0, int nval, u32x4 (&xw)[24]) __attribute__((always_inline)) {
+    auto issue_x = [&](int vrow0, u32x4 (&xw)[24]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int item = j * 64 + lane, r = item >> 3, pc = item & 7;
-            const unsigned base = r < nval ? (unsigned)((grow0 + r) * (C * 2) + pc * 16) : OOB;
+            const unsigned base = vrow0 + r < N ? (unsigned)(grow_of(vrow0 + r) * (C * 2) + pc * 16) : OOB;
 #pragma unroll
             for (int s = 0; s < 6; ++s) xw[s * 4 + j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, base, s * 128, 0));
         }
     };
     u32x4 xw[24];
-    if (tv[0]) issue_x(tg0[0], tnv[0], xw);
+    if (tv[0]) issue_x(trow[0], xw);
     // the head's q bias through LDS (read back, 16 bytes per register quad, when a tile's accumulators are done)
     float* const BQ = reinterpret_cast<float*>(lds + hs_bias_offset(U, kc));
     if (tid < DH) BQ[tid] = p.bq ? p.bq[h * DH + tid] : 0.f;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
                 for (int t = 0; t < 3; ++t) qa[t] = mfma16<F16>(fa[s & 1][3 * j + t], fb[s & 1][j], qa[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (e == 0 && tv[1]) issue_x(tg0[1], tnv[1], xw);  // the second tile's rows travel under the rotation of the first
+        if (e == 0 && tv[1]) issue_x(trow[1], xw);  // the second tile's rows travel under the rotation of the first
         if (e == 0 && p.rope_mode >= 0) {
             // in revolutions per position unit (the attention kernel's inv_rev table, same expression): pair index 16g + dl(i),
             // dl(i) = (i & 3) + 8 (i >> 2) + 4 lh, for register i < 8 and pair group g < 3
@@ -257,9 +261,11 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
                 r16x2<F16>(qv[t][4 * qd + 2], qv[t][4 * qd + 3]);
             }
         if (p.rope_mode >= 0) {
-            const int nqu = tu[e] ? nq[U - 1] : nq[0];
+            const int v = trow[e] + lr;                    // this lane's virtual row: its utterance, and its position inside it
+            const bool in1 = U > 1 && v >= nq0;
+            const int nqu = in1 ? nq[U - 1] : nq0;
             const float pscale = p.rope_mode == 1 ? p.gamma / (float)(nqu > 0 ? nqu : 1) : 1.f;
-            const float pp = (float)(trow[e] + lr) * pscale;
+            const float pp = (float)(in1 ? v - nq0 : v) * pscale;
             auto rot = [&](float& a0, float& a1, float fr) __attribute__((always_inline)) {
                 const float rev = __builtin_amdgcn_fractf(pp * fr);
                 const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
@@ -312,13 +318,9 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
     const int ksw = ((lr >> 2) & 3) << 4;                                // this lane's K row swizzle
     const int vtr = ((lr & 15) >> 2) * HS_RB + ((lr >> 4) * 16 + (lr & 3) * 4) * 2;  // its address inside a transposed-read block
     bf16x8 oB[2][6];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        if (!tv[e]) continue;
-        const unsigned char* const Kb = KV + tu[e] * SLOT;
-        const unsigned char* const Vb = Kb + kc * HS_RB;
-        const int nku = tu[e] ? nk[U - 1] : nk[0];
-        f32x16 sc[4];
+    // S^T of one 32-row tile against slot `slot`'s keys: all six K fragments of a key tile are read before its MFMAs
+    auto scores = [&](int slot, const bf16x8 (&q)[6], f32x16 (&sc)[4]) __attribute__((always_inline)) {
+        const unsigned char* const Kb = KV + slot * SLOT;
         // this lane's four swizzled chunk positions inside a 64-byte group of its K row: chunk c sits at kq[c & 3] + 64 (c >> 2)
         const unsigned char* kq[4];
 #pragma unroll
@@ -336,16 +338,59 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) sc[kt] = mfma16<F16>(__builtin_bit_cast(bf16x8, ka[ks]), qB[e][ks], sc[kt]);
+                for (int ks = 0; ks < 6; ++ks) sc[kt] = mfma16<F16>(__builtin_bit_cast(bf16x8, ka[ks]), q[ks], sc[kt]);
             }
         }
-        // masked maximum, exponentials and their sum: element i of key tile kt is key 32kt + (i & 3) + 8 (i >> 2) + 4 lh; only the key
-        // tile that holds the context's end needs the comparison (wave-uniform)
+    };
+    // O^T += V_slot^T P^T for one key tile: V^T[d = 32nd + lr][keys 16sidx + 4lh + {0..3} and + 8] by two transposed reads of 4 keys x 16
+    // dims per operand, all six operands of the key tile read before its MFMAs
+    auto pv_tile = [&](int slot, int kt, const float (&pr)[16], f32x16 (&oa)[3]) __attribute__((always_inline)) {
+        const unsigned char* const Vb = KV + slot * SLOT + kc * HS_RB;
+        u32x4 va[2][3];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const unsigned char* const vb = Vb + (kt * 32 + 16 * sidx + 4 * lh) * HS_RB + vtr;
+#pragma unroll
+            for (int nd = 0; nd < 3; ++nd) {
+                const uint2 lo = ld_tr(vb + nd * 64), hi = ld_tr(vb + nd * 64 + 8 * HS_RB);
+                va[sidx][nd] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const bf16x8 pb = pk8<F16>(&pr[8 * sidx]);
+#pragma unroll
+            for (int nd = 0; nd < 3; ++nd) oa[nd] = mfma16<F16>(__builtin_bit_cast(bf16x8, va[sidx][nd]), pb, oa[nd]);
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (!tv[e]) continue;
+        // which contexts the tile's rows belong to (wave-uniform), and this lane's own
+        const bool has0 = trow[e] < nq0, has1 = U > 1 && min(trow[e] + 32, N) > nq0;
+        const bool both = has0 && has1;
+        const int s0 = has0 ? 0 : 1;                     // the (first) slot of the tile
+        const bool in1 = U > 1 && trow[e] + lr >= nq0;   // this lane's row is slot 1's
+        const int nku = in1 ? nk[U - 1] : nk[0];         // its context length
+        const int nk_s0 = s0 ? nk[U - 1] : nk[0];
+        f32x16 sc[4];
+        scores(s0, qB[e], sc);
+        if (both) {  // a tile that straddles the two utterances: the other context too, each lane keeps its own scores
+            f32x16 sc1[4];
+            scores(1, qB[e], sc1);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < nkt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[kt][i] = in1 ? sc1[kt][i] : sc[kt][i];
+        }
+        // masked maximum, exponentials and their sum: element i of key tile kt is key 32kt + (i & 3) + 8 (i >> 2) + 4 lh; only a key
+        // tile that holds the context's end needs the comparison (wave-uniform; a straddling tile always compares)
         float m = -1e30f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
             if (kt < nkt) {
-                if (kt * 32 + 32 <= nku) {
+                if (!both && kt * 32 + 32 <= nk_s0) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) m = fmaxf(m, sc[kt][i]);
                 } else {
@@ -364,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
                 float pr[16];
                 // (v_exp_f32 flushes results below 2^-126 to zero where exp2f returns a denormal: the same 16-bit value, and a sum that holds
                 // the maximum's 1.0 does not see the difference)
-                if (kt * 32 + 32 <= nku) {
+                if (!both && kt * 32 + 32 <= nk_s0) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { pr[i] = __builtin_amdgcn_exp2f(sc[kt][i] - m); lsum += pr[i]; }
                 } else {
@@ -374,23 +419,14 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
                         lsum += pr[i];
                     }
                 }
-                // V^T[d = 32nd + lr][keys 16sidx + 4lh + {0..3} and + 8] of this key tile: two transposed reads of 4 keys x 16 dims per
-                // operand, all six operands of the key tile read before its MFMAs
-                u32x4 va[2][3];
+                if (!both) {
+                    pv_tile(s0, kt, pr, oa);
+                } else {  // each context's values weigh only its own lanes' exponentials
+                    float p0[16], p1[16];
 #pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx) {
-                    const unsigned char* const vb = Vb + (kt * 32 + 16 * sidx + 4 * lh) * HS_RB + vtr;
-#pragma unroll
-                    for (int nd = 0; nd < 3; ++nd) {
-                        const uint2 lo = ld_tr(vb + nd * 64), hi = ld_tr(vb + nd * 64 + 8 * HS_RB);
-                        va[sidx][nd] = u32x4{lo.x, lo.y, hi.x, hi.y};
-                    }
-                }
-#pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx) {
-                    const bf16x8 pb = pk8<F16>(&pr[8 * sidx]);
-#pragma unroll
-                    for (int nd = 0; nd < 3; ++nd) oa[nd] = mfma16<F16>(__builtin_bit_cast(bf16x8, va[sidx][nd]), pb, oa[nd]);
+                    for (int i = 0; i < 16; ++i) { p0[i] = in1 ? 0.f : pr[i]; p1[i] = in1 ? pr[i] : 0.f; }
+                    pv_tile(0, kt, p0, oa);
+                    pv_tile(1, kt, p1, oa);
                 }
             }
         lsum += __shfl_xor(lsum, 32, 64);
@@ -449,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
             for (int k = 0; k < 8; ++k) {
                 const int row = 4 * k + srow;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(IMG + row * HS_IS + scol);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, row < tnv[e] ? (unsigned)((tg0[e] + row) * (C * 2) + c * 256 + scol) : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, trow[e] + row < N ? (unsigned)(grow_of(trow[e] + row) * (C * 2) + c * 256 + scol) : OOB, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -458,6 +494,26 @@ __global__ __launch_bounds__(256, 1) void xattn_hs_kernel(HsArgs p) {
         __builtin_amdgcn_s_waitcnt(0);
         unsigned long long* tp = p.ts + (size_t)blockIdx.x * 8;
         tp[0] = t0; tp[1] = t1; tp[2] = t2; tp[3] = t3; tp[4] = t4; tp[5] = t5; tp[6] = __builtin_readcyclecounter(); tp[7] = (unsigned long long)T;
+    }
+}
+
+// Pairs for the head-split launch: utterances sorted by length (ties: by index), the k-th longest paired with the k-th shortest — the
+// sums of a pair's lengths, hence its row tiles, are as equal as the batch allows.  pairs[2g], pairs[2g + 1] (-1: the odd one out).
+__global__ __launch_bounds__(1024) void hs_pairs_kernel(const int* __restrict__ len, int B, int* __restrict__ pairs) {
+    __shared__ int l[1024], sorted[1024];
+    const int i = threadIdx.x;
+    if (i < B) l[i] = len[i];
+    __syncthreads();
+    if (i < B) {
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (l[j] < l[i] || (l[j] == l[i] && j < i)) ? 1 : 0;
+        sorted[rank] = i;  // ascending
+    }
+    __syncthreads();
+    const int G = (B + 1) / 2;
+    if (i < G) {
+        pairs[2 * i] = sorted[B - 1 - i];
+        pairs[2 * i + 1] = B - 1 - i > i ? sorted[i] : -1;
     }
 }
 
@@ -482,13 +538,19 @@ int hs_group(int B, int L, int kc) {
 
 }  // namespace
 
+int xattn_hs_group(int B, int L, int Lk) { return hs_group(B, L, (Lk + 31) & ~31); }
+void launch_xattn_hs_pairs(hipStream_t s, const int* qlen, int B, int* pairs) {
+    if (B < 1 || B > 1024) throw std::invalid_argument("launch_xattn_hs_pairs: 1 <= B <= 1024");
+    STN_KLAUNCH(hs_pairs_kernel, dim3(1), dim3(1024), 0, s, qlen, B, pairs);
+}
+
 bool xattn_hs_supported(int dtype, int C, int H, int L, int Lk, int ldk) {
     return is_half(dtype) && C == HS_C && H == HS_H && L >= 1 && L <= 256 && Lk >= 1 && Lk <= 128 && ldk % 8 == 0;
 }
 
 void launch_xattn_hs(hipStream_t s, int dtype, const void* xn, int64_t M, const void* WqF, const float* bq, const void* kp, const void* vp, int ldk,
                      const void* WoA, void* part, int64_t part_stride, int B, int L, int Lk, const int* qlen, const int* klen,
-                     const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma, unsigned long long* ts) {
+                     const int* q_off, const int* k_off, int rope_mode, float rope_base, float rope_gamma, unsigned long long* ts, const int* pairs) {
     if (B == 0 || L == 0 || M == 0) return;
     if (!xattn_hs_supported(dtype, HS_C, HS_H, L, Lk, ldk) || !qlen || !q_off || (k_off && !klen) || !part || part_stride < M * HS_C ||
         M * HS_C * 2 >= 0x7FFFFFFFll || (int64_t)B * Lk * ldk * 2 >= 0x7FFFFFFFll ||
@@ -502,7 +564,7 @@ void launch_xattn_hs(hipStream_t s, int dtype, const void* xn, int64_t M, const 
     a.kc = (Lk + 31) & ~31;
     const int U = hs_group(B, L, a.kc);
     a.G = (B + U - 1) / U; a.Gpad = (a.G + 7) & ~7;
-    a.qlen = qlen; a.klen = klen; a.q_off = q_off; a.k_off = k_off;
+    a.qlen = qlen; a.klen = klen; a.q_off = q_off; a.k_off = k_off; a.pairs = pairs;
     a.rope_mode = rope_mode; a.log_base = logf(rope_base); a.gamma = rope_gamma; a.ts = ts;
     const size_t lds = (size_t)hs_lds_bytes(U, a.kc);
     if (dtype == F16) { if (U == 2) hs_launch<true, 2>(s, a, lds); else hs_launch<true, 1>(s, a, lds); }
