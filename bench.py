@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch utterances per GPU; strong: --batch utterances in all")
     ap.add_argument("--no-host-loop", action="store_true", help="skip the host-to-host loop (value_host)")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-utterance record (config C2)")
+    ap.add_argument("--eager", action="store_true", help="launch every step eagerly instead of replaying the captured hipGraphs (profiler runs: rocprofv3's kernel "
+                                                         "trace of many graph launches crashes inside the ROCm 7.2 runtime; kernel durations are the same)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0: pick a free one)")
     return ap.parse_args()
 
@@ -207,6 +209,8 @@ def main():
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
         eng.set_stream(side.cuda_stream)
+    if args.eager:
+        eng.set_graph_mode(False)
     eng.batch_upload(ids, mask, sttl, sdp, duration_override=durs, utt_ids=mine)
 
     gather_buf = {}
@@ -511,7 +515,9 @@ def main():
             eng.set_graph_mode(False)
             eng.batch_run(args.total_step, args.speed, 1234)
             eng.sync()
-            eng.profile_filter(None)
+            # family tags only: a filter that no family matches keeps every launch free of events (the profiler times the kernels itself;
+            # event-carrying dispatch packets — hipExtLaunchKernelGGL — under rocprofv3's interception crash inside the ROCm 7.2 runtime)
+            eng.profile_filter("-")
             eng.profile_sample(1)
             eng.profile_enable(True)
             eng.launch_log_enable(True)

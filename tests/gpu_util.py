@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BOUNDS_PATH = os.path.join(_HERE, "golden", "parity_bounds.json")
 # Generic ceilings (relative to the oracle output's rms) — what the arithmetic mode can promise; a case listed in
 # tests/golden/parity_bounds.json is held to ITS bound instead: <= 2x what tools/parity_record.py measured on an MI355X
-# (profiles/parity_r03.json), never looser than the ceiling.
+# (profiles/parity_r04.json), never looser than the ceiling.
 CEILING = {"f32": dict(stage=(2e-4, 5e-5), e2e=(2e-3, 5e-4)),
            "bf16": dict(stage=(1e-1, 2e-2), e2e=(3e-1, 5e-2)),
            "f16": dict(stage=(1.5e-2, 3e-3), e2e=(4e-2, 8e-3))}

@@ -1,5 +1,5 @@
 """The parity bounds the GPU tests assert (tests/golden/parity_bounds.json) against the errors measured on an MI355X
-(profiles/parity_r03.json, written by tools/parity_record.py): every bound is at most 2x its measurement (or the fp32
+(profiles/parity_r04.json, written by tools/parity_record.py): every bound is at most 2x its measurement (or the fp32
 summation-noise floor, max 2e-6 / rms 5e-7 of the output's rms) and at least the measurement itself, every measured case has a bound, and no bound is looser than the arithmetic mode's ceiling."""
 import json
 import os
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bounds_are_at_most_twice_the_measured_error():
-    with open(os.path.join(ROOT, "profiles", "parity_r03.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "parity_r04.json")) as f:
         measured = json.load(f)["measured"]
     with open(BOUNDS_PATH) as f:
         bounds = json.load(f)["bounds"]

@@ -4,7 +4,7 @@
 
 Runs the oracle-parity tests (tests/test_gpu_stages.py, tests/test_gpu_configs.py, tests/test_gpu_load_dir.py, tests/test_gpu_ffn.py) once with STN_PARITY_RECORD set — the tests'
 own inputs, engines and comparison code, so what is recorded is exactly what the tests assert on — and writes
-  parity_r03.json     {"measured": {case: {dtype: {"max", "rms", "kind", "n"}}}, "_source_sha": ...}   -> commit as profiles/parity_r03.json
+  parity_r04.json     {"measured": {case: {dtype: {"max", "rms", "kind", "n"}}}, "_source_sha": ...}   -> commit as profiles/parity_r04.json
   parity_bounds.json  {"bounds": {case: {dtype: {"max", "rms"}}}}: 2 x measured, rounded DOWN to two digits, not below
                       FLOOR (fp32 summation-order noise)                                                      -> tests/golden/
 (max, rms) are relative to the rms of the oracle's output (tests/gpu_util.rel_err).  tests/test_parity_bounds_cpu.py keeps the
@@ -56,10 +56,10 @@ def main():
               for c, per in measured.items()}
     note = ("relative to the rms of the oracle output (tests/gpu_util.rel_err); tiny = tests' small descriptor, c1/c3/c4/c5 = the 66 M stack on "
             "BASELINE.json's configs; engine through the C ABI vs oracle/stn_ref.c on identical synthetic weights and inputs")
-    with open(os.path.join(args.out_dir, "parity_r03.json"), "w") as f:
+    with open(os.path.join(args.out_dir, "parity_r04.json"), "w") as f:
         json.dump({"_source_sha": source_sha(), "note": note, "measured": measured}, f, indent=1, sort_keys=True)
     with open(os.path.join(args.out_dir, "parity_bounds.json"), "w") as f:
-        json.dump({"source": "profiles/parity_r03.json (tools/parity_record.py): bound = max(2 x measured rounded down to two digits, floor)",
+        json.dump({"source": "profiles/parity_r04.json (tools/parity_record.py): bound = max(2 x measured rounded down to two digits, floor)",
                    "floor": FLOOR, "bounds": bounds},
                   f, indent=1, sort_keys=True)
     for c in sorted(measured):

@@ -30,7 +30,7 @@ def find(d, pat):
 
 def base(kname):
     """'void stn::v_x::gemm_tiled_kernel<1, 128>(...)' or 'stn::gemm_tiled_kernel' -> 'gemm_tiled_kernel'"""
-    k = kname.split("(")[0].split("<")[0].strip()
+    k = kname.replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].strip()
     return k.split(" ")[-1].split("::")[-1]
 
 
@@ -127,6 +127,25 @@ def main():
                 mu[f] = {"mfma_util": round(sum(u) / len(u), 4), "launches": len(u), "mfma_busy_cycles_per_launch": round(sum(busy[f]) / len(busy[f]), 1),
                          "gui_active_per_launch": round(sum(act[f]) / len(act[f]), 1)}
         json.dump(mu, open(os.path.join(ROOT, "profiles", "mfma_util.json"), "w"), indent=1)
+    # L2 hit rate per family (TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), MI355X_MICROARCH.md): where a kernel's bytes come from — its
+    # XCD's L2 or beyond it (Infinity Cache / HBM)
+    rows, m = load_pass(a.dir, "pmc_tcc*counter_collection.csv", "log_tcc.json", "Dispatch_Id", "Kernel_Name")
+    if rows:
+        hit, miss = {}, {}
+        for r in rows:
+            f = m.get(int(r["Dispatch_Id"]))
+            if not f or f == "-":
+                continue
+            if r["Counter_Name"] == "TCC_HIT_sum":
+                hit.setdefault(f, []).append(float(r["Counter_Value"]))
+            elif r["Counter_Name"] == "TCC_MISS_sum":
+                miss.setdefault(f, []).append(float(r["Counter_Value"]))
+        l2 = {"_source_sha": sha, "_tag": a.tag, "_note": "per launch, averaged over the family's launches of one fully tagged step; requests are 128-byte lines"}
+        for f in sorted(hit):
+            if f in miss and len(miss[f]) == len(hit[f]):
+                h_, m_ = sum(hit[f]) / len(hit[f]), sum(miss[f]) / len(miss[f])
+                l2[f] = {"l2_hit_rate": round(h_ / max(h_ + m_, 1.0), 4), "tcc_hit_per_launch": round(h_, 1), "tcc_miss_per_launch": round(m_, 1), "launches": len(hit[f])}
+        json.dump(l2, open(os.path.join(ROOT, "profiles", "l2_hit.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", f"{a.tag}_families.csv"), "w") as f:
         f.write("family,launches,avg_us,total_us,fetch_kib_raw,write_kib,hbm_bytes_per_launch\n")
         for k, e in sorted(fam.items(), key=lambda kv: -kv[1].get("rocprof_total_us", 0)):
