@@ -348,7 +348,7 @@ def main():
         avg_ms = st["ms"] / max(st["launches"], 1)
         flops_per_launch = st["flops"] / max(st["launches"], 1)
         bytes_per_launch = st["bytes"] / max(st["launches"], 1)
-        is_gemm = "gemm" in dominant or "attention" in dominant or "ffn" in dominant
+        is_gemm = "gemm" in dominant or "attention" in dominant or "ffn" in dominant or "xattn" in dominant
         if is_gemm:
             peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -473,7 +473,7 @@ def main():
             other = {}
             for k, v in top:
                 ms = v["ms"] / max(v["launches"], 1)
-                if "gemm" in k or "attention" in k or "ffn" in k:
+                if "gemm" in k or "attention" in k or "ffn" in k or "xattn" in k:
                     peak = 2500.0 if args.dtype in ("bf16", "f16") else 157.3
                     a_ = v["flops"] / max(v["launches"], 1) / (ms * 1e-3) / 1e12
                     other[k] = {"bound": "mfma", "achieved": round(a_, 1), "unit": "TFLOP/s", "frac": round(a_ / peak, 4), "avg_us": round(ms * 1e3, 1)}
