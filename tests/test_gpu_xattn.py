@@ -35,12 +35,14 @@ def _batch_latent(eng, mode, ids, mask, sttl, sdp, fd, steps, noise):
 
 
 @pytest.mark.parametrize("dtype,tol_max,tol_rms", [("bf16", 6e-2, 8e-3), ("f16", 8e-3, 1e-3)])
-@pytest.mark.parametrize("n,min_words,max_words,dur_scale", [(5, 1, 9, 1.0), (70, 4, 12, 1.0), (66, 10, 15, 1.0), (3, 14, 16, 2.0)])
+@pytest.mark.parametrize("n,min_words,max_words,dur_scale", [(5, 1, 9, 1.0), (70, 4, 12, 1.0), (67, 2, 13, 1.0), (66, 10, 15, 1.0), (3, 14, 16, 2.0)])
 def test_head_split_equals_four_launches(dtype, tol_max, tol_rms, n, min_words, max_words, dur_scale):
     """Packed resident batch, two Euler steps: the latent of the head-split blocks against the four-launch blocks.  The two forms round
     the same intermediates (q, rotated q, exponentials, attention output) and differ by the 16-bit rounding of the per-head partial sums.
-    Cases: one utterance per workgroup (5 and 3 utterances; the 3 long ones have up to 8 row tiles: two per wave), pairs of utterances
-    per workgroup (70 short ones), pairs with more than four tiles (66 utterances of 65-128 frames: some waves own two tiles)."""
+    Cases: one utterance per workgroup (5 and 3 utterances; the 3 long ones have up to 6 row tiles: two per wave), pairs of utterances
+    per workgroup chosen longest-with-shortest, their rows one virtual sequence (70 short ones; 67: an odd count, the median utterance
+    alone in its workgroup, and very short ones — a pair can fit one tile), pairs with more than four tiles (66 utterances of up to 103
+    frames: some waves own two tiles, most tiles straddle the two utterances)."""
     arch, ids, mask, sttl, sdp, durs, D, L, lens, lm = _inputs(n, min_words, max_words, 100 + n)
     if dur_scale != 1.0:  # slower speech: more latent frames for the same text (more than four row tiles per utterance)
         durs = durs * np.float32(dur_scale)
