@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <set>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -219,6 +220,7 @@ int stn_group_synthesize(stn_group* g, int B, int Lt, const int64_t* text_ids, c
     if (B < 1 || Lt < 1 || !text_ids || !text_mask || !style_ttl || !style_dp || total_step < 1 || !(speed > 0.f))
         return fail(g, STN_ERR_INVALID, "stn_group_synthesize: B, Lt, total_step >= 1, speed > 0 and non-null inputs");
     const int n = (int)g->ranks.size();
+    g->B = 0;  // (a failed synthesis leaves nothing to fetch)
     stn_arch a;
     if (stn_get_arch(g->ranks[0].h, &a) != STN_OK) return fail(g, STN_ERR_STATE, std::string("stn_group_synthesize: ") + stn_last_error(g->ranks[0].h));
     const size_t ttl_n = (size_t)a.n_style_ttl * a.d_style_ttl, dp_n = (size_t)a.n_style_dp * a.d_style_dp;

@@ -86,6 +86,24 @@ def test_more_devices_than_the_box_has_is_an_error():
         binding.Group([0, 0, n], "bf16")
 
 
+def test_a_rank_failure_names_the_rank_and_leaves_nothing_to_fetch():
+    arch, ids, mask, sttl, sdp, durs = _c3_like(5, 8)
+    g = binding.Group([0, 0], "bf16")
+    g.load_synthetic(arch, 7)
+    pcm, _ = g.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=durs, noise_seed=5)
+    bad = durs.copy()
+    bad[binding.group_deal(mask.sum(axis=(1, 2)).astype(np.int32), 2)[0] == 1] = 0.0  # rank 1's shard: not a duration
+    with pytest.raises(binding.StnError) as ei:
+        g.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=bad, noise_seed=5)
+    assert "rank 1" in str(ei.value) and "device 0" in str(ei.value) and "duration override must be > 0" in str(ei.value)
+    out = np.zeros(pcm.size, np.int16)
+    rc = g._lib.stn_group_fetch_pcm16(g._g, out.ctypes.data, out.size, None)
+    assert rc == -3 and b"no synthesis" in g._lib.stn_group_last_error(g._g)  # STN_ERR_STATE: the earlier result is not handed out as this one's
+    pcm2, _ = g.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=durs, noise_seed=5)  # and the group is usable afterwards
+    assert np.array_equal(pcm, pcm2)
+    g.close()
+
+
 def test_cli_gpus_flag(tmp_path):
     exe = os.path.join(ROOT, "supertonic_amd", "example_native")
     n = binding.device_count()
