@@ -1,5 +1,6 @@
 // engine.cpp — weights, workspace and the four stage executors (see engine.hpp).
 #include "engine.hpp"
+#include "dev_env.hpp"
 #include "engine_internal.hpp"
 
 #include <algorithm>
@@ -109,7 +110,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     // handles in flight (53 k -> 34 k audio-s/s: two highest-priority queues no longer interleave) — not adopted
     int prio_least = 0, prio_greatest = 0;
     STN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    const char* pr = getenv("STN_PRIO");
+    const char* pr = stn::dev_env("STN_PRIO");
     auto prio_of = [&](char c) { return c == 'h' ? prio_greatest : c == 'l' ? prio_least : 0; };
     const int prio_main = pr && pr[0] ? prio_of(pr[0]) : 0, prio_side = pr && pr[0] && pr[1] ? prio_of(pr[1]) : 0;
     STN_HIP(hipStreamCreateWithPriority(&own_s_, hipStreamNonBlocking, prio_main));
@@ -119,16 +120,16 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     STN_HIP(hipEventCreateWithFlags(&ev_copied_, hipEventDisableTiming));
     STN_HIP(hipEventCreateWithFlags(&ev_dp_, hipEventDisableTiming));
     STN_HIP(hipStreamCreateWithPriority(&te_s_, hipStreamNonBlocking, prio_side));
-    if (const char* p = getenv("STN_DP_STREAM")) if (atoi(p) == 0) {  // A/B switch: everything on the main stream
+    if (const char* p = stn::dev_env("STN_DP_STREAM")) if (atoi(p) == 0) {  // A/B switch: everything on the main stream
         (void)hipStreamDestroy(dp_s_); dp_s_ = nullptr;
         (void)hipStreamDestroy(te_s_); te_s_ = nullptr;
     }
-    if (const char* p = getenv("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
-    if (const char* p = getenv("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
-    if (const char* p = getenv("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
-    if (const char* p = getenv("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks head-split (default) or as four launches (0)
-    if (const char* p = getenv("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
-    if (const char* p = getenv("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
+    if (const char* p = stn::dev_env("STN_NT")) nt_hints_ = atoi(p) != 0;  // A/B switch: non-temporal hints on the vocoder's hidden activation
+    if (const char* p = stn::dev_env("STN_FFN")) fused_ffn_ = atoi(p);          // A/B switch: K4 stage mask (1 vocoder, 2 estimator, 4 text stages)
+    if (const char* p = stn::dev_env("STN_FFN_MIN_ROWS")) ffn_min_rows_ = atoll(p);
+    if (const char* p = stn::dev_env("STN_XATTN")) set_fused_xattn(atoi(p));  // A/B switch: cross-attention blocks head-split (default) or as four launches (0)
+    if (const char* p = stn::dev_env("STN_FFN_SPLIT_MIN_ROWS")) ffn_split_min_rows_ = atoll(p);
+    if (const char* p = stn::dev_env("STN_PACKED")) packed_ve_ = atoi(p) != 0;  // A/B switch for measurements (stn_set_row_layout overrides)
 }
 
 void Engine::set_stream(hipStream_t s) {

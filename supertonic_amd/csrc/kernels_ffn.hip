@@ -31,6 +31,7 @@
 // hand-over of stage s+1 (counted vmcnt, raw s_barrier, refill of the stage vacated two stages ago) sits in the MIDDLE of
 // stage s, so the last block of a stage can already read the first fragments of the next one: no bubble at a stage seam.
 #include "kernels.hpp"
+#include "dev_env.hpp"
 #include "kernels_dev.hpp"
 
 #include <stdio.h>
@@ -291,7 +292,7 @@ bool ffn_split_valid(int dtype, int C, int I, int S) {
 // bit for bit (include/stn.h).
 int ffn_split_choose(int dtype, int C, int I, int64_t M) {
     if (ffn_split_factor(dtype, C, I) < 2) return 0;
-    static const int force = [] { const char* e = getenv("STN_FFN_SPLIT_S"); return e ? atoi(e) : 0; }();  // A/B switch
+    static const int force = [] { const char* e = stn::dev_env("STN_FFN_SPLIT_S"); return e ? atoi(e) : 0; }();  // A/B switch
     const int64_t nslab = (M + 127) / 128;
     const int want = force ? force : nslab <= 16 ? 12 : 4;
     return ffn_split_valid(dtype, C, I, want) ? want : 4;
@@ -307,7 +308,7 @@ static void launch_ffn_t(hipStream_t s, int dtype, const FfnArgs& a) {
     const int nslab = (a.M + 127) / 128;
     const dim3 grid(a.split > 1 ? (unsigned)((nslab + 7) / 8 * 8 * a.split) : (unsigned)nslab);
 #ifdef STN_FFN_VARIANTS
-    static const int var = [] { const char* e = getenv("STN_FFN_VAR"); return e ? atoi(e) : 0; }();
+    static const int var = [] { const char* e = stn::dev_env("STN_FFN_VAR"); return e ? atoi(e) : 0; }();
     auto go = [&](auto kern) {
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(ffn_fused variant)");
         STN_KLAUNCH(kern, grid, dim3(256), lds, s, a);

@@ -19,6 +19,7 @@
 // Workgroup -> tile map is XCD-aware: the tiles that share an A row-panel are consecutive and land on
 // one XCD (private 4 MiB L2), the bijective remap of the CDNA4 guide.
 #include "kernels.hpp"
+#include "dev_env.hpp"
 #include "kernels_dev.hpp"
 
 #include <hip/hip_bf16.h>
@@ -837,7 +838,7 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
         else launch_tiled<MODE, 128, 128, 2, 2, 3, 32, 4>(s, A, lda, W, ldw, M, N, K, e);
         return true;
     }
-    if (g_gemm_cfg == -2) { const char* c = getenv("STN_GEMM_CFG"); g_gemm_cfg = c ? atoi(c) : -1; }
+    if (g_gemm_cfg == -2) { const char* c = stn::dev_env("STN_GEMM_CFG"); g_gemm_cfg = c ? atoi(c) : -1; }
     int cfg = g_gemm_cfg;
     if (cfg < 0) {
         // measured on MI355X (tools/gemm_bench.py): the 256x256 tile halves the operand bytes per FLOP and wins whenever
@@ -855,7 +856,7 @@ static bool launch_tiled_auto(hipStream_t s, int dtype, const void* A, int lda, 
     }
     if ((cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 12 || cfg == 13 || cfg == 14) && K % 64) return false;
     static int g_tr = -2;
-    if (g_tr == -2) { const char* c = getenv("STN_GEMM_TR"); g_tr = c ? atoi(c) : 1; }
+    if (g_tr == -2) { const char* c = stn::dev_env("STN_GEMM_TR"); g_tr = c ? atoi(c) : 1; }
     Epilogue et = e;
     // the transposed-image epilogue stores 64-byte row segments (16 rows per instruction): a win where a CU runs one tile
     // (-4 % ve.pw1, -15 % te.pw1), a loss where a co-resident workgroup's K loop competes for the vector-memory path (vo.pw1)

@@ -8,6 +8,7 @@
 //   + gather / mask / transpose / noise / pcm helpers.
 // All row-major [rows][channels]; see kernels.hpp for the contracts.
 #include "kernels.hpp"
+#include "dev_env.hpp"
 #include "kernels_fold.hpp"
 
 #include <hip/hip_bf16.h>
@@ -338,7 +339,7 @@ static void launch_dwconv_ln_v3_kr(hipStream_t s, const float* x, int nseq, int 
                                    const int* row_off = nullptr) {
     const int wps = ((L + R * dil - 1) / (R * dil)) * dil;
     const int64_t nw = (int64_t)nseq * wps;
-    static const int xcd_runs = [] { const char* e = getenv("STN_DWCONV_XCD"); return e ? atoi(e) : 1; }();  // A/B switch
+    static const int xcd_runs = [] { const char* e = stn::dev_env("STN_DWCONV_XCD"); return e ? atoi(e) : 1; }();  // A/B switch
     STN_KLAUNCH((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
                        dil, wps, g, b, eps, y, seqlen, row_off, xcd_runs);
 }
@@ -703,7 +704,7 @@ static void launch_fold_dwconv_ln_t3(hipStream_t s, const float* x_in, float* x_
     if (attr_once.need())
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024), "hipFuncSetAttribute(fold_dwconv_ln)");
-    static const int force = [] { const char* e = getenv("STN_FOLD_TCH"); return e ? atoi(e) : 0; }();  // A/B switch: 8 or 32
+    static const int force = [] { const char* e = stn::dev_env("STN_FOLD_TCH"); return e ? atoi(e) : 0; }();  // A/B switch: 8 or 32
     const int tch = force == FOLD_TCH || force == FOLD_TCH_FEW ? force : (int64_t)B * ((L + FOLD_TCH - 1) / FOLD_TCH) < 64 ? FOLD_TCH_FEW : FOLD_TCH;
     const int cps = (L + tch - 1) / tch;
     STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil, tch), s, x_in, x_out, cps, C,

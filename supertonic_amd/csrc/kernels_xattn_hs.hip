@@ -35,6 +35,7 @@
 // front of every LDS access that follows an LDS-DMA, which would serialise the prefetches this kernel lives on — K/V travel under the
 // q projection, Wo under the attention.
 #include "kernels.hpp"
+#include "dev_env.hpp"
 #include "kernels_dev.hpp"
 
 #include <algorithm>
@@ -529,7 +530,7 @@ void hs_launch(hipStream_t s, const HsArgs& a, size_t lds) {
 // utterances per workgroup: two when one per workgroup would need more than one round of workgroups on the chip (and the pair's K / V
 // slots fit beside Wo_h); a pair's tiles must fit the two a wave can own (<= 128 rows per utterance)
 int hs_group(int B, int L, int kc) {
-    static const int force = [] { const char* e = getenv("STN_XATTN_HS_U"); return e ? atoi(e) : 0; }();  // A/B switch
+    static const int force = [] { const char* e = stn::dev_env("STN_XATTN_HS_U"); return e ? atoi(e) : 0; }();  // A/B switch
     const bool can2 = L <= 128 && (size_t)hs_lds_bytes(2, kc) <= 160 * 1024;
     if (force == 1 || !can2) return 1;
     if (force == 2) return 2;

@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 
 def _single_stream_engine(arch, dtype):
     os.environ["STN_DP_STREAM"] = "0"
+    os.environ["STN_DEV_SWITCHES"] = "1"  # (the master switch the measurement switches need: csrc/dev_env.hpp)
     try:
         e = binding.Engine(0, dtype)
     finally:
-        del os.environ["STN_DP_STREAM"]
+        del os.environ["STN_DP_STREAM"], os.environ["STN_DEV_SWITCHES"]
     e.load_synthetic(arch, 7)
     return e
 

@@ -1,5 +1,5 @@
-"""Every diagnostic switch of the engine (environment variables read at stn_create / at a kernel's first launch; DESIGN.md "Switches") is a
-configuration somebody will run: each one is driven here through a whole synthesis of the default (full-width) descriptor in a fresh process and
+"""Every diagnostic switch of the engine (environment variables read at stn_create / at a kernel's first launch, honoured only beside the master
+switch STN_DEV_SWITCHES=1: csrc/dev_env.hpp) is a configuration somebody will run: each one is driven here through a whole synthesis of the default (full-width) descriptor in a fresh process and
 held against the default configuration — bit-equal where the switch only moves work between streams, within the dtype's recorded bound where it
 picks another kernel form (stn.h, "WHAT IS AND IS NOT BIT-IDENTICAL").  A malformed value must not take the process down either."""
 import json
@@ -62,11 +62,13 @@ SWITCHES = [
 ]
 
 
-def _run(tmp, tag, env_extra):
+def _run(tmp, tag, env_extra, master=True):
     env = dict(os.environ)
-    for k in [s[0] for s in SWITCHES]:
+    for k in [s[0] for s in SWITCHES] + ["STN_DEV_SWITCHES"]:
         env.pop(k, None)
     env.update(env_extra)
+    if env_extra and master:
+        env["STN_DEV_SWITCHES"] = "1"
     prefix = os.path.join(tmp, tag)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, prefix], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (tag, r.stdout[-2000:], r.stderr[-4000:])
@@ -74,6 +76,7 @@ def _run(tmp, tag, env_extra):
     res = json.loads(line[7:])
     for dt in res:
         res[dt]["wav"] = np.load(prefix + "_" + dt + ".npy")
+    res["stderr"] = r.stderr
     return res
 
 
@@ -81,12 +84,21 @@ def test_every_environment_switch_against_the_default(tmp_path):
     tmp = str(tmp_path)
     base = _run(tmp, "default", {})
     again = _run(tmp, "default2", {})
-    for dt in base:
+    dts = [k for k in base if k != "stderr"]
+    for dt in dts:
         assert base[dt]["sha"] == again[dt]["sha"], dt   # process-to-process determinism of the default
+    # a switch without the master is named on stderr and changes nothing: the default configuration's bits and launch shapes
+    stray = _run(tmp, "stray", {"STN_FFN": "0", "STN_XATTN": "0", "STN_PACKED": "0"}, master=False)
+    for dt in dts:
+        assert stray[dt]["sha"] == base[dt]["sha"] and stray[dt]["rows"] == base[dt]["rows"], dt
+    for name in ("STN_FFN", "STN_XATTN", "STN_PACKED"):
+        assert stray["stderr"].count(name + "=0 ignored") == 1, stray["stderr"][-2000:]
+    assert "ignored" not in base["stderr"]
     bounds = {"bf16": 6e-2, "f32": 5e-5}
     for i, (name, val, kind) in enumerate(SWITCHES):
         got = _run(tmp, "s%d" % i, {name: val})
-        for dt in base:
+        assert "ignored" not in got["stderr"]
+        for dt in dts:
             # the predictor runs fp32 in every engine: its durations are bit-equal under the switches that only move work, and equal to fp32
             # rounding under those that change a launch's row count or tile (padded text rows leave the M <= 512 split-K regime of the fp32 GEMM:
             # another summation order, stn.h "WHAT IS AND IS NOT BIT-IDENTICAL")

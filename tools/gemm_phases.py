@@ -1,7 +1,7 @@
 """In-kernel phase breakdown of the tiled GEMM on the model's shapes (stn_op_gemm_phases): where a launch spends its time.
 Ticks are shader-clock cycles of the workgroup's own CU (s_memtime; counters of different XCDs are not comparable, so only
 per-workgroup differences are reported).
-Usage: python tools/gemm_phases.py [modes...]     (on a GPU box; STN_GEMM_CFG=<n> forces a tile configuration)
+Usage: python tools/gemm_phases.py [modes...]     (on a GPU box; STN_DEV_SWITCHES=1 STN_GEMM_CFG=<n> forces a tile configuration)
 modes: 0 bias+GELU->bf16, 1 residual epilogue, 2 bias only, 3 fp32 store"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
