@@ -39,7 +39,8 @@ int stn_group_create(int n_devices, const int* devices_or_null, int dtype, stn_g
 int stn_group_destroy(stn_group* g);
 const char* stn_group_last_error(const stn_group* g_or_null);
 int stn_group_size(const stn_group* g);
-/* 1 when the gather runs over RCCL (more than one distinct device), 0 for one device or a rehearsal on shared devices */
+/* 1 when the gather runs over RCCL (more than one distinct device; or one device under the measurement switch STN_GROUP_SELF_RCCL=1, which sends the
+ * block to itself), 0 for one device or a rehearsal on shared devices */
 int stn_group_uses_rccl(const stn_group* g);
 /* rank r's engine handle (settings, diagnostics); owned by the group */
 stn_handle* stn_group_handle(stn_group* g, int rank);

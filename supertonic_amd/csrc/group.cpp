@@ -2,6 +2,7 @@
 // device; length-sorted round-robin deal; 16-bit PCM gathered into the first device over RCCL; caller-order result on the host).
 // Stands in for the batch dimension of /root/reference/cpp/helper.cpp:477 spread over the GPUs of a node.
 #include "../../include/stn_group.h"
+#include "dev_env.hpp"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -72,6 +73,8 @@ struct Rank {
 struct stn_group {
     std::vector<Rank> ranks;
     bool rccl = false;
+    bool self_rccl = false;  // measurement switch STN_GROUP_SELF_RCCL=1 on a group of one: the root's own block travels through ncclSend / ncclRecv to itself,
+                             // so a one-GPU box executes the library calls of the exchange (dlopen, ncclCommInitAll, grouped send / receive on the stream)
     Rccl nccl;
     std::vector<ncclComm_t> comms;
     void* host_stage = nullptr;  // pinned: all blocks back to back
@@ -176,6 +179,7 @@ int stn_group_create(int n_devices, const int* devices, int dtype, stn_group** o
             if (stn_set_stream(k.h, k.stream) != STN_OK) throw std::runtime_error(stn_last_error(k.h));
         }
         g->rccl = n_devices > 1 && (int)distinct.size() == n_devices;
+        if (n_devices == 1) { const char* e = stn::dev_env("STN_GROUP_SELF_RCCL"); g->self_rccl = g->rccl = e && atoi(e) == 1; }
         if (n_devices > 1 && !g->rccl && distinct.size() != 1) {
             // (a mix of shared and distinct devices would need both exchange forms at once: not a configuration anyone runs)
             stn_group_destroy(g);
@@ -281,10 +285,11 @@ int stn_group_synthesize(stn_group* g, int B, int Lt, const int64_t* text_ids, c
         // ---- the one exchange: every other rank's block into the first device's memory -------------------------------------------
         Rank& root = g->ranks[0];
         HIPG(hipSetDevice(root.device));
-        for (int r = 1; r < n; ++r) grow(&g->ranks[r].recv, &g->ranks[r].recv_cap, (size_t)g->ranks[r].B * g->ranks[r].W * sizeof(int16_t));
+        const int first_peer = g->self_rccl ? 0 : 1;
+        for (int r = first_peer; r < n; ++r) grow(&g->ranks[r].recv, &g->ranks[r].recv_cap, (size_t)g->ranks[r].B * g->ranks[r].W * sizeof(int16_t));
         if (g->rccl) {
             ncclResult_t nr = g->nccl.GroupStart();
-            for (int r = 1; r < n && nr == ncclSuccess; ++r) {
+            for (int r = first_peer; r < n && nr == ncclSuccess; ++r) {
                 const size_t bytes = (size_t)g->ranks[r].B * g->ranks[r].W * sizeof(int16_t);
                 if (!bytes) continue;
                 nr = g->nccl.Send(g->ranks[r].send, bytes, ncclInt8, 0, g->comms[r], g->ranks[r].stream);      // rank r -> 0, on r's stream
@@ -314,7 +319,7 @@ int stn_group_synthesize(stn_group* g, int B, int Lt, const int64_t* text_ids, c
         for (int r = 0; r < n; ++r) {
             Rank& k = g->ranks[r];
             const size_t bytes = (size_t)k.B * k.W * sizeof(int16_t);
-            if (bytes) HIPG(hipMemcpyAsync(static_cast<char*>(g->host_stage) + off, r == 0 ? k.send : k.recv, bytes, hipMemcpyDeviceToHost, root.stream));
+            if (bytes) HIPG(hipMemcpyAsync(static_cast<char*>(g->host_stage) + off, r < first_peer ? k.send : k.recv, bytes, hipMemcpyDeviceToHost, root.stream));
             off += bytes;
         }
         for (Rank& k : g->ranks) {

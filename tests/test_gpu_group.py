@@ -1,7 +1,8 @@
 """include/stn_group.h on a GPU box: the group path at N = 1 against stn_batch_fetch_pcm16 byte for byte; the multi-rank path
 rehearsed on one GPU (ranks share the device, the gather is a device copy: deal, worker threads, block layout and the reorder into
 caller order are the real path's) against single-engine syntheses of exactly the dealt shards; refusal of more devices than the box
-has; the C++ host and CLI with --gpus / --devices.  The RCCL exchange itself needs more than one GPU and has not run here."""
+has; the C++ host and CLI with --gpus / --devices; the RCCL calls of the exchange with one rank sending to itself.  Two or more RCCL ranks need
+as many GPUs and have not run here."""
 import os
 import subprocess
 
@@ -102,6 +103,42 @@ def test_a_rank_failure_names_the_rank_and_leaves_nothing_to_fetch():
     pcm2, _ = g.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=durs, noise_seed=5)  # and the group is usable afterwards
     assert np.array_equal(pcm, pcm2)
     g.close()
+
+
+SELF_RCCL_CHILD = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from supertonic_amd import binding, host, workload
+from supertonic_amd.arch import default_arch
+arch = default_arch()
+texts = workload.utterances(12, min_words=3, max_words=12, seed=3)
+ids, mask = host.UnicodeProcessor(host.synthetic_indexer())(texts, ["en"] * 12)
+sttl, sdp = workload.synthetic_styles(arch, list(range(12)))
+g = binding.Group(1, "bf16")
+g.load_synthetic(arch, 7)
+for seed in (99, 100):   # twice: the communicator and the receive block are reused
+    pcm, dur = g.synthesize(ids, mask, sttl, sdp, 3, 1.05, duration_override=workload.forced_durations(texts), noise_seed=seed)
+    print("RESULT", int(g.uses_rccl), hashlib.sha256(pcm.tobytes()).hexdigest(), int(np.abs(pcm.astype(np.int32)).max()))
+g.close()
+"""
+
+
+def test_the_rccl_calls_of_the_exchange_on_one_gpu(tmp_path):
+    """A group of one whose own block goes through ncclSend / ncclRecv to itself (measurement switch STN_GROUP_SELF_RCCL=1): librccl is opened, the
+    communicator created, a grouped send / receive enqueued on the engine's stream and the received block fetched — the bytes are the plain group's.
+    More than one rank needs more than one GPU and has not run here."""
+    import sys
+    outs = []
+    for extra in ({}, {"STN_DEV_SWITCHES": "1", "STN_GROUP_SELF_RCCL": "1"}):
+        env = dict(os.environ); env.pop("STN_GROUP_SELF_RCCL", None); env.pop("STN_DEV_SWITCHES", None); env.update(extra)
+        r = subprocess.run([sys.executable, "-c", SELF_RCCL_CHILD, ROOT], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-4000:])
+        outs.append([l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")])
+    plain, via = outs
+    assert len(plain) == 2 and len(via) == 2
+    assert all(p[1] == "0" for p in plain) and all(v[1] == "1" for v in via)   # uses_rccl
+    assert [p[2] for p in plain] == [v[2] for v in via] and all(int(p[3]) > 0 for p in plain)
 
 
 def test_cli_gpus_flag(tmp_path):
