@@ -37,6 +37,11 @@ probe: build/pk_probe
 build/pk_probe: tools/probe/pk_probe.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -o $@ $<
+# L2 -> CU ingest rate with every CU streaming (the wall DESIGN.md section 9.1 prices the fused FFN kernels against; run on a GPU box: build/l2_ingest_probe)
+probe-ingest: build/l2_ingest_probe
+build/l2_ingest_probe: tools/probe/l2_ingest_probe.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
 # Sanitizer build of the host-side parsers (CPU only; no GPU sanitizer exists on this pool): everything under csrc/host/ that reads
 # caller-supplied files and strings — the protobuf reader, the graph binder, the JSON reader, the text frontend, the voice-style loader —
@@ -56,4 +61,4 @@ clean:
 	rm -rf build build_asan supertonic_amd/libstn.so supertonic_amd/example_native
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean probe host-asan
+.PHONY: all oracle clean probe probe-ingest host-asan
