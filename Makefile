@@ -42,6 +42,11 @@ probe-ingest: build/l2_ingest_probe
 build/l2_ingest_probe: tools/probe/l2_ingest_probe.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
+# the fixed cost of one dependent launch in a replayed graph (empty, with the fused kernels' resources, producer / consumer): build/launch_floor_probe
+probe-launch: build/launch_floor_probe
+build/launch_floor_probe: tools/probe/launch_floor_probe.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -o $@ $<
 
 # Sanitizer build of the host-side parsers (CPU only; no GPU sanitizer exists on this pool): everything under csrc/host/ that reads
 # caller-supplied files and strings — the protobuf reader, the graph binder, the JSON reader, the text frontend, the voice-style loader —
@@ -61,4 +66,4 @@ clean:
 	rm -rf build build_asan supertonic_amd/libstn.so supertonic_amd/example_native
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean probe probe-ingest host-asan
+.PHONY: all oracle clean probe probe-ingest probe-launch host-asan

@@ -105,6 +105,7 @@ Engine::Engine(int device, int dtype) : device_(device), dt_(dtype) {
     if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the engine has no CPU fallback");
     if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
     STN_HIP(hipSetDevice(device));
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) n_cu_ = cu; else (void)hipGetLastError(); }
     // Stream priorities, experiment switch STN_PRIO=<main><side>, each h / n / l (default nn: all streams at the default priority).  Measured:
     // the main stream at the highest priority gains 0.6 % for one batch at a time (11.59 -> 11.52 ms) and LOSES a third of the rate with two
     // handles in flight (53 k -> 34 k audio-s/s: two highest-priority queues no longer interleave) — not adopted
@@ -555,6 +556,7 @@ void Engine::convnext(const ConvNeXt& p, float* x, int B, int L, int C, int hid,
     if (fs && fs->pending) {
         // the previous block's pointwise pair is still a set of partial sums: this block's conv kernel folds it on the way in
         if (prof_on_) prof_begin("fold_dwconv_ln", (double)M * C * (2.0 * k + 8 + 2.0 * fs->fold.S), (double)M * C * (8.0 + 2.0 + 2.0 * fs->fold.S));
+        fs->fold.run_frames = rg->fold_run;
         launch_fold_dwconv_ln(s_, dt_, fs->x, fs->x_alt, B, L, C, fs->fold, p.dw_t, p.dw_b, k, dil, p.ln.g, p.ln.b, a_.ln_eps, xn, len, rg->off);
         if (prof_on_) prof_end();
         std::swap(fs->x, fs->x_alt);

@@ -104,7 +104,8 @@ class Engine {
     // Packed ("ragged") latent rows: utterance b owns rows off[b] .. off[b] + llen[b] and no padding rows exist; `rows` is
     // their total.  The masked stages are row-independent, so this is an exact optimisation of the padded [b*L + t] layout.
     struct Ragged { const int* off = nullptr; const int* row_b = nullptr; int rows = 0;
-                    const int* hs_pairs = nullptr; };  // (latent rows) which two utterances share a workgroup of the head-split cross-attention
+                    const int* hs_pairs = nullptr;  // (latent rows) which two utterances share a workgroup of the head-split cross-attention
+                    int fold_run = 0; };            // (latent rows) run length of fold_dwconv_ln's workgroups for these lengths (fold_run_frames; 0: default)
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                      const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr,
                      const Ragged* rg = nullptr, const float* dt = nullptr /* 1/total_step per utterance, if precomputed */);
@@ -327,6 +328,7 @@ class Engine {
     void prof_end();
 
     int device_, dt_;
+    int n_cu_ = 256;  // compute units of the device (launch shapes that depend on rounds of workgroups)
     hipStream_t s_ = nullptr, own_s_ = nullptr;
     const char* stage_ = "";
     std::string prof_filter_;

@@ -339,6 +339,8 @@ void Engine::enqueue_after_duration(int total_step, const std::function<void()>&
         int* row_b = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)std::max(rg.rows, 1)));
         launch_row_map(s_, b.llen, B, off, row_b, rg.rows);
         rg.off = off; rg.row_b = row_b;
+        // one 1024-thread workgroup of fold_dwconv_ln fits a CU: 271 runs of <= 32 frames (this bench's lengths) are two rounds, 256 runs of <= 40 one
+        rg.fold_run = fold_run_frames(b.h_llen.data(), B, n_cu_);
         if (fused_xattn_ && is_half(dt_) && B >= 2) {  // the head-split cross-attention's pairing, once per synthesis (the lengths are the run's)
             int* pairs = static_cast<int*>(ar_.alloc(sizeof(int) * (size_t)(B + 2)));
             launch_xattn_hs_pairs(s_, b.llen, B, pairs);

@@ -156,7 +156,12 @@ struct FoldArgs {
     const float* rowvec = nullptr; int rv_ld = 0;  // per-sequence vector or null
     const int* row_b = nullptr;       // fold_ln with rowvec: sequence of row m
     unsigned long long* ts = nullptr; // diagnostics (fold_dwconv_ln): 4 shader-clock stamps per workgroup — entry, phase 1 done, hand-over, end
+    int run_frames = 0;               // fold_dwconv_ln: longest run of frames a workgroup takes (0: the default, 32; fold_run_frames() picks it from the lengths)
 };
+// fold_dwconv_ln puts ONE 1024-thread workgroup on a CU, so a launch of 257 workgroups takes two rounds where 256 take one (12.6 -> 16.2 us at
+// the bench's shape).  The run length that gives the fewest rounds over `n_cu` compute units for these sequence lengths — 32, 40 or 48 frames; the
+// smallest among equals (longer runs are longer workgroups).  A frame's arithmetic does not depend on the run it falls in: same bits for any choice.
+int fold_run_frames(const int* lengths, int B, int n_cu);
 // x (in place) <- folded x;  y <- LayerNorm(folded x)       (rows are independent)
 void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, const FoldArgs& f, const float* g, const float* b, float eps, void* y);
 // packed rows only (row_off / seqlen as launch_dwconv_ln): x_out <- folded x_in (x_out != x_in: a workgroup re-folds the halo rows

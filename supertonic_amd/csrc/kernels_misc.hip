@@ -529,7 +529,7 @@ void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, co
 // the x_out stores are the last thing a thread issues.
 // Few sequences (a single utterance: two workgroups) are cut into runs of 8 frames instead: more workgroups, one pass of phase-1 loads each
 // instead of two to four dependent ones; a frame's arithmetic does not depend on the run it falls in, so the result is the same bit for bit.
-static constexpr int FOLD_TCH = 32, FOLD_TCH_FEW = 8, FOLD_NT = 1024;  // FOLD_TCH == 2 * wavefronts per workgroup (the longest run)
+static constexpr int FOLD_TCH = 32, FOLD_TCH_FEW = 8, FOLD_TCH_MAX = 48, FOLD_NT = 1024;  // FOLD_TCH == 2 * wavefronts per workgroup (the longest run)
 template <typename OutT, bool F16, int K, bool RV, int FOLD_NSLOT /* float4 slots per lane of a half wavefront: ceil(C / 128) */, int S>
 __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __restrict__ xin, float* __restrict__ xout, int cps, int C,
                                                                  const uint16_t* __restrict__ part, int64_t pstride,
@@ -567,7 +567,10 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     }
     // ---- phase 1: a thread keeps ONE 8-channel group (its b2 / gamma / time-vector values are loaded once) and walks down the
     // window rows, `rpp` rows apart; every load of U rows is issued before the first use ----
-    constexpr int U = S <= 4 ? 2 : 1;  // (more splits: one row at a time, the partial sums in chunks of 12 loads)
+    // Three rows per thread and trip when there are four partial sums: a run of 29 frames with a halo of 2 x 16 (dilation 8) is 61 rows = ONE trip of
+    // 3 x 21 rows — one global round trip instead of two dependent ones.  The third row's loads are issued only by the threads that have one.
+    // (the wider variants — C = 512, seven taps — keep two rows: three would spill; more splits: one row at a time, the partial sums in chunks of 12 loads)
+    constexpr int U = S <= 4 ? (K == 5 && FOLD_NSLOT <= 3 ? 3 : 2) : 1;
     const int rpp = FOLD_NT / C8;  // rows per pass of the workgroup
     const int c8 = tid % C8, rq = tid / C8;
     if (rq < rpp) {
@@ -584,30 +587,44 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
             for (int u = 0; u < U; ++u) {
                 const int r = min(r0 + u * rpp, nw - 1);  // (past the end: the last row again, stored nowhere)
                 mrow[u] = row0 + w0 + r;
-                const float4* xp = reinterpret_cast<const float4*>(xin + mrow[u] * C + c8 * 8);
-                xa[u][0] = xp[0]; xa[u][1] = xp[1];
             }
-            if constexpr (U == 2) {  // every load of both rows is issued before the first use
+            if constexpr (U >= 2) {  // every load of all rows is issued before the first use
                 constexpr int CH = S;
-                unsigned w[2][CH][4];
+                uint4 w[U][CH];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u) {
+                    const float4* xp = reinterpret_cast<const float4*>(xin + mrow[u] * C + c8 * 8);
+                    xa[u][0] = xp[0]; xa[u][1] = xp[1];
+#pragma unroll
+                    for (int sp = 0; sp < CH; ++sp) w[u][sp] = *reinterpret_cast<const uint4*>(part + (size_t)sp * pstride + (size_t)mrow[u] * C + c8 * 8);
+                }
+                if constexpr (U == 3) {
+                    if (r0 + 2 * rpp < nw) {
+                        const float4* xp = reinterpret_cast<const float4*>(xin + mrow[2] * C + c8 * 8);
+                        xa[2][0] = xp[0]; xa[2][1] = xp[1];
+#pragma unroll
+                        for (int sp = 0; sp < CH; ++sp) w[2][sp] = *reinterpret_cast<const uint4*>(part + (size_t)sp * pstride + (size_t)mrow[2] * C + c8 * 8);
+                    } else {
+                        xa[2][0] = xa[2][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int sp = 0; sp < CH; ++sp) w[2][sp] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int sp = 0; sp < CH; ++sp) {
-                        const uint4 q = *reinterpret_cast<const uint4*>(part + (size_t)sp * pstride + (size_t)mrow[u] * C + c8 * 8);
-                        w[u][sp][0] = q.x; w[u][sp][1] = q.y; w[u][sp][2] = q.z; w[u][sp][3] = q.w;
-                    }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int sp = 0; sp < CH; ++sp)
+                        const unsigned wj[4] = {w[u][sp].x, w[u][sp].y, w[u][sp].z, w[u][sp].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float lo = p16_to_f<F16>(w[u][sp][j] & 0xFFFFu), hi = p16_to_f<F16>(w[u][sp][j] >> 16);
+                            const float lo = p16_to_f<F16>(wj[j] & 0xFFFFu), hi = p16_to_f<F16>(wj[j] >> 16);
                             if (sp == 0) { acc[u][2 * j] = lo; acc[u][2 * j + 1] = hi; }
                             else { acc[u][2 * j] += lo; acc[u][2 * j + 1] += hi; }
                         }
+                    }
             } else {
+                const float4* xp = reinterpret_cast<const float4*>(xin + mrow[0] * C + c8 * 8);
+                xa[0][0] = xp[0]; xa[0][1] = xp[1];
                 fold_sum<F16, 8, S>(part + (size_t)mrow[0] * C + c8 * 8, pstride, acc[0]);
             }
 #pragma unroll
@@ -633,10 +650,12 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     // ---- phase 2: one frame per HALF wavefront (32 lanes x FOLD_NSLOT float4 slots cover C): all of a run's <= 32 frames are done
     // in one pass of the 16 wavefronts, and the two LayerNorm reductions are 4 DPP steps + one swizzle over 32 lanes ----
     const int lane = tid & 63, l32 = lane & 31;
-    const int t = t0 + 2 * (tid >> 6) + (lane >> 5);
+    const float4* ws4 = reinterpret_cast<const float4*>(wsm);
+    for (int tp = t0; tp < t1; tp += FOLD_TCH) {  // (a run longer than 32 frames — run_frames 40 / 48 — takes a second pass)
+    asm volatile("" ::: "memory");  // (keeps the pass's LDS reads of the taps and LayerNorm parameters inside it: hoisted, they would spill)
+    const int t = tp + 2 * (tid >> 6) + (lane >> 5);
     const bool live = t < t1;
     const int tl = live ? t : t0;  // (a half wavefront beyond the run computes frame t0 again and stores nothing)
-    const float4* ws4 = reinterpret_cast<const float4*>(wsm);
     float4 h[FOLD_NSLOT];
 #pragma unroll
     for (int i = 0; i < FOLD_NSLOT; ++i) {
@@ -676,6 +695,7 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
             }
         }
     }
+    }
     // ---- the folded frames this run owns -> x_out (each thread: the image rows it wrote itself) ----
     if (rq < rpp)
         for (int r = rq; r < nw; r += rpp) {
@@ -692,6 +712,19 @@ __global__ __launch_bounds__(FOLD_NT) void fold_dwconv_ln_kernel(const float* __
     }
 }
 
+int fold_run_frames(const int* lengths, int B, int n_cu) {
+    if (!lengths || B <= 0 || n_cu <= 0) return 0;
+    int best = 0;
+    long best_rounds = 0;
+    for (int tch = FOLD_TCH; tch <= FOLD_TCH_MAX; tch += 8) {
+        long n = 0;
+        for (int i = 0; i < B; ++i) n += (std::max(lengths[i], 0) + tch - 1) / tch;
+        const long rounds = (n + n_cu - 1) / n_cu;
+        if (!best || rounds < best_rounds) { best = tch; best_rounds = rounds; }
+    }
+    return best == FOLD_TCH ? 0 : best;
+}
+
 static size_t fold_dwconv_lds(int C, int k, int dil, int tch = FOLD_TCH) { return ((size_t)(tch + (k - 1) * dil) + 1 + (size_t)(k + 3)) * C * 4; }  // image + zero row + parameter block
 bool fold_dwconv_ln_supported(int C, int k, int dil) {
     return C % 8 == 0 && C <= 512 && (k == 5 || k == 7) && dil >= 1 && fold_dwconv_lds(C, k, dil) <= 160 * 1024;
@@ -704,8 +737,11 @@ static void launch_fold_dwconv_ln_t3(hipStream_t s, const float* x_in, float* x_
     if (attr_once.need())
         stn_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024), "hipFuncSetAttribute(fold_dwconv_ln)");
-    static const int force = [] { const char* e = stn::dev_env("STN_FOLD_TCH"); return e ? atoi(e) : 0; }();  // A/B switch: 8 or 32
-    const int tch = force == FOLD_TCH || force == FOLD_TCH_FEW ? force : (int64_t)B * ((L + FOLD_TCH - 1) / FOLD_TCH) < 64 ? FOLD_TCH_FEW : FOLD_TCH;
+    static const int force = [] { const char* e = stn::dev_env("STN_FOLD_TCH"); return e ? atoi(e) : 0; }();  // A/B switch: 8, 32, 40 or 48
+    int tch = force == FOLD_TCH || force == FOLD_TCH_FEW ? force : (int64_t)B * ((L + FOLD_TCH - 1) / FOLD_TCH) < 64 ? FOLD_TCH_FEW : FOLD_TCH;
+    if ((force == 40 || force == 48) && fold_dwconv_lds(C, K, dil, force) <= 160 * 1024) tch = force;
+    if (!force && tch == FOLD_TCH && f.run_frames > FOLD_TCH && f.run_frames <= FOLD_TCH_MAX && f.run_frames % 8 == 0 && fold_dwconv_lds(C, K, dil, f.run_frames) <= 160 * 1024)
+        tch = f.run_frames;  // fewer rounds of workgroups for these lengths (fold_run_frames)
     const int cps = (L + tch - 1) / tch;
     STN_KLAUNCH((fold_dwconv_ln_kernel<OutT, F16, K, RV, NSLOT, S>), dim3((unsigned)((int64_t)B * cps)), dim3(FOLD_NT), fold_dwconv_lds(C, K, dil, tch), s, x_in, x_out, cps, C,
                 static_cast<const uint16_t*>(f.part), f.part_stride, f.b2, f.gamma, f.rowvec, f.rv_ld, w_t, bias, dil, g, b, eps, 1.0f / (float)C, y, seqlen, row_off, f.ts, tch);

@@ -54,6 +54,8 @@ SWITCHES = [
     ("STN_XATTN", "0", "bound"),           # the cross-attention blocks as four launches instead of head-split
     ("STN_FOLD_TCH", "8", "equal"),        # the fold kernel's run length: the same bits either way
     ("STN_FOLD_TCH", "32", "equal"),
+    ("STN_FOLD_TCH", "40", "equal"),       # (two passes of the conv / LayerNorm phase for runs longer than 32 frames)
+    ("STN_FOLD_TCH", "48", "equal"),
     ("STN_DWCONV_XCD", "0", "equal"),      # tile order of the comb kernel: placement only
     ("STN_PRIO", "hn", "equal"),           # stream priorities: scheduling only
     ("STN_PRIO", "ll", "equal"),
