@@ -1,9 +1,10 @@
 // Probe: what does ONE dependent launch cost on this chip, beyond the work of its workgroups?
 // A hipGraph of N kernel nodes in a chain (each depends on the one before, like the pipeline's launches), replayed; time per node for
 //   - an empty kernel (1 workgroup; 256 workgroups of 256 threads; 256 workgroups of 1024 threads),
-//   - the same grid with the resources of the fused FFN kernel (131 KB of LDS, ~500 VGPRs: one workgroup per CU),
+//   - the same grid with the LDS of the fused FFN kernel (131 KB: one workgroup per CU),
 //   - a grid whose workgroups each WRITE `wkb` KB (the end-of-kernel write-back of dirty L2 lines is inside the launch),
-//   - a grid whose workgroups each READ what the previous node wrote (the producer / consumer pattern of K4-split and the fold kernels).
+//   - read-only nodes, and nodes of one load + one store per thread whose source is static or the previous node's output (the producer /
+//     consumer pattern of K4-split and the fold kernels: reading what the node before wrote costs nothing extra).
 // DESIGN.md section 9.0 prices the pipeline's launch boundaries with these numbers.   build: make probe-launch   run: build/launch_floor_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -30,20 +31,6 @@ __global__ void k_write(uint4* dst, int vec_per_wg) {
     uint4* d = dst + (size_t)blockIdx.x * vec_per_wg;
     for (int i = threadIdx.x; i < vec_per_wg; i += blockDim.x) d[i] = make_uint4(i, 1, 2, 3);
 }
-// reads the rows ANOTHER workgroup (shuffle != 0) or the same workgroup index (shuffle == 0) of an earlier node wrote; four loads in flight per lane
-__global__ void k_readwrite(const uint4* src, uint4* dst, int vec_per_wg, int shuffle) {
-    const uint4* s = src + (size_t)(shuffle ? (blockIdx.x * 37 + 11) % gridDim.x : blockIdx.x) * vec_per_wg;
-    uint4* d = dst + (size_t)blockIdx.x * vec_per_wg;
-    const int n = blockDim.x;
-    int i = threadIdx.x;
-    for (; i + 3 * n < vec_per_wg; i += 4 * n) {
-        uint4 v0 = s[i], v1 = s[i + n], v2 = s[i + 2 * n], v3 = s[i + 3 * n];
-        v0.x += 1; v1.x += 1; v2.x += 1; v3.x += 1;
-        d[i] = v0; d[i + n] = v1; d[i + 2 * n] = v2; d[i + 3 * n] = v3;
-    }
-    for (; i < vec_per_wg; i += n) { uint4 v = s[i]; v.x += 1; d[i] = v; }
-}
-
 // reads only (the sum is stored by nobody: the compare never matches)
 __global__ void k_read(const uint4* src, unsigned* sink, int vec_per_wg) {
     const uint4* s = src + (size_t)blockIdx.x * vec_per_wg;
@@ -94,33 +81,19 @@ int main() {
     chain("empty kernel, 256 workgroups x 256", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, s, dp); });
     chain("empty kernel, 256 workgroups x 1024", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(1024), 0, s, dp); });
     chain("empty kernel, 2048 workgroups x 256", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_empty, dim3(2048), dim3(256), 0, s, dp); });
-    chain("fat kernel (131 KB LDS, ~500 VGPRs), 256 workgroups x 256", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_fat, dim3(256), dim3(256), 131 * 1024, s, dp, 0); });
+    chain("empty kernel with 131 KB of LDS per workgroup, 256 workgroups x 256", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_fat, dim3(256), dim3(256), 131 * 1024, s, dp, 0); });
     uint4* stat;
     CK(hipMalloc(&stat, bufbytes)); CK(hipMemset(stat, 0, bufbytes));
-    uint4* ring[4];
-    ring[0] = b0; ring[1] = b1;
-    CK(hipMalloc(&ring[2], bufbytes)); CK(hipMalloc(&ring[3], bufbytes));
-    CK(hipMemset(ring[2], 0, bufbytes)); CK(hipMemset(ring[3], 0, bufbytes));
     chain("256 x 1024 READ-ONLY 16 KB each of a buffer nobody writes", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_read, dim3(256), dim3(1024), 0, s, stat, (unsigned*)dp, 1024); });
     chain("256 x 1024 READ-ONLY 96 KB each of a buffer nobody writes", N, [&](hipStream_t s, int) { hipLaunchKernelGGL(k_read, dim3(256), dim3(1024), 0, s, stat, (unsigned*)dp, 6144); });
     chain("256 x 1024 one load + one store per thread, static source, alternating destinations", N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_copy1, dim3(256), dim3(1024), 0, s, stat, (i & 1) ? b1 : b0); });
     chain("256 x 1024 one load + one store per thread, previous node's output", N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_copy1, dim3(256), dim3(1024), 0, s, (i & 1) ? b0 : b1, (i & 1) ? b1 : b0); });
     chain("1 x 64 one load + one store per thread, previous node's output", N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_copy1, dim3(1), dim3(64), 0, s, (i & 1) ? b0 : b1, (i & 1) ? b1 : b0); });
-    for (int wkb : {16, 96}) {
+    for (int wkb : {16, 96, 256}) {
         char lab[160];
         const int vec = wkb * 1024 / 16;
         snprintf(lab, sizeof lab, "256 x 256 each WRITE %d KB (%.1f MB per node)", wkb, 256.0 * wkb / 1024);
         chain(lab, N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, s, (i & 1) ? b1 : b0, vec); });
-        for (int th : {256, 1024}) {
-            snprintf(lab, sizeof lab, "256 x %d each READ %d KB of a buffer nobody writes, WRITE %d KB", th, wkb, wkb);
-            chain(lab, N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_readwrite, dim3(256), dim3(th), 0, s, stat, (i & 1) ? b1 : b0, vec, 1); });
-            snprintf(lab, sizeof lab, "256 x %d each READ %d KB the previous node wrote (other workgroup), WRITE %d KB", th, wkb, wkb);
-            chain(lab, N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_readwrite, dim3(256), dim3(th), 0, s, (i & 1) ? b0 : b1, (i & 1) ? b1 : b0, vec, 1); });
-            snprintf(lab, sizeof lab, "256 x %d each READ %d KB the previous node wrote (same workgroup index), WRITE %d KB", th, wkb, wkb);
-            chain(lab, N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_readwrite, dim3(256), dim3(th), 0, s, (i & 1) ? b0 : b1, (i & 1) ? b1 : b0, vec, 0); });
-            snprintf(lab, sizeof lab, "256 x %d each READ %d KB written THREE nodes ago (other workgroup), WRITE %d KB", th, wkb, wkb);
-            chain(lab, N, [&](hipStream_t s, int i) { hipLaunchKernelGGL(k_readwrite, dim3(256), dim3(th), 0, s, ring[(i + 1) & 3], ring[i & 3], vec, 1); });
-        }
     }
     return 0;
 }
