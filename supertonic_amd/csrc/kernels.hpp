@@ -159,8 +159,9 @@ struct FoldArgs {
     int run_frames = 0;               // fold_dwconv_ln: longest run of frames a workgroup takes (0: the default, 32; fold_run_frames() picks it from the lengths)
 };
 // fold_dwconv_ln puts ONE 1024-thread workgroup on a CU, so a launch of 257 workgroups takes two rounds where 256 take one (12.6 -> 16.2 us at
-// the bench's shape).  The run length that gives the fewest rounds over `n_cu` compute units for these sequence lengths — 32, 40 or 48 frames; the
-// smallest among equals (longer runs are longer workgroups).  A frame's arithmetic does not depend on the run it falls in: same bits for any choice.
+// the bench's shape).  The run length whose GRID (B x ceil(longest / run): the placeholders of runs a sequence does not have take a CU each on their way
+// out) fits ONE round of `n_cu` workgroups — 40 or 48 frames where 32 does not; 0 (the default) otherwise: with several rounds either way the count
+// of rounds stops predicting the time.  A frame's arithmetic does not depend on the run it falls in: same bits for any choice.
 int fold_run_frames(const int* lengths, int B, int n_cu);
 // x (in place) <- folded x;  y <- LayerNorm(folded x)       (rows are independent)
 void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, const FoldArgs& f, const float* g, const float* b, float eps, void* y);
