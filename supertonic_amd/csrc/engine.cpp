@@ -813,7 +813,7 @@ float* Engine::ve_time_cond_dev(int rows, const float* total_step, const float* 
 
 void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                          const float* total_step, const float* current_step, float* denoised, const float* tb, const Ragged* rg,
-                         const float* dt) {
+                         const float* dt, void* z_rows, bool z_ready, bool z_next) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, D = a.latent_dim * a.chunk_compress_factor, nb = a.ve_main_blocks, H = a.ve_heads;
@@ -823,8 +823,9 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     const size_t esz = is_half(dt_) ? 2 : 4;
     const Arena::Mark mk = ar_.mark();
     const int Dp = (D + 63) / 64 * 64;
-    void* z = act_alloc(M * Dp);
-    launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z, Dp, llen, roff);
+    // the latent as rows for the input projection: the caller's persistent buffer when the step before left it there (euler_ncl writes both layouts)
+    void* z = z_rows ? z_rows : act_alloc(M * Dp);
+    if (!(z_rows && z_ready)) launch_ncl_to_rows(s_, dt_, noisy, B, D, L, z, Dp, llen, roff);
     FoldState fs;  // the residual stream (and, with K4-split blocks, its pending update)
     fs.x = f32_alloc(M * C);
     {
@@ -921,7 +922,7 @@ void Engine::ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const
     float* vel = f32_alloc(M * D);
     Epilogue eo; eo.mode = EPI_STORE; eo.out_dtype = F32; eo.out = vel; eo.ldo = D;
     gemm("gemm_out", dt_, xn, C, linear("ve.out"), (int)M, eo);
-    launch_euler_ncl(s_, noisy, vel, dtv, llen, B, D, L, denoised, roff);
+    launch_euler_ncl(s_, noisy, vel, dtv, llen, B, D, L, denoised, roff, (z_rows && z_next) ? z_rows : nullptr, dt_, Dp);
     ar_.release(mk);
 }
 

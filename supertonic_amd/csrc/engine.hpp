@@ -108,7 +108,10 @@ class Engine {
                     int fold_run = 0; };            // (latent rows) run length of fold_dwconv_ln's workgroups for these lengths (fold_run_frames; 0: default)
     void ve_step_dev(int B, int L, const VeCtx& c, const float* noisy, const int* tlen, const int* llen,
                      const float* total_step, const float* current_step, float* denoised, const float* tb = nullptr,
-                     const Ragged* rg = nullptr, const float* dt = nullptr /* 1/total_step per utterance, if precomputed */);
+                     const Ragged* rg = nullptr, const float* dt = nullptr /* 1/total_step per utterance, if precomputed */,
+                     void* z_rows = nullptr /* [rows][D padded to 64] act, columns >= D zero: persistent across the steps of one synthesis */,
+                     bool z_ready = false /* z_rows already holds `noisy` as rows (the step before wrote it) */,
+                     bool z_next = false /* write `denoised` into z_rows as rows for the step after */);
     // vlen (optional, device [B]): valid vocoder frames per utterance — the length-aware mode (see set_vocoder_mode)
     // vrows > 0 (with vlen): run the vocoder on packed rows — vrows = sum of vlen — and unpack into the padded wav at the end
     // valid (with vlen, vrows): the exact trimmed DENSE mode — rows are computed on vlen[b] frames, exact below valid[b], and

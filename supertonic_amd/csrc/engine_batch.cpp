@@ -349,9 +349,14 @@ void Engine::enqueue_after_duration(int total_step, const std::function<void()>&
         rgp = &rg;
     }
     int cur = 0;
+    // the latent as rows (the input projection's operand) lives across the steps: every step's Euler update writes it beside the [B][D][L] layout, so only
+    // the first step converts (ncl_to_rows: 11 us of strided reads per step otherwise)
+    const int Dz = (a.latent_dim * a.chunk_compress_factor + 63) / 64 * 64;
+    const int64_t Mz = rgp ? (int64_t)rg.rows : (int64_t)B * L;
+    void* z_rows = act_alloc(Mz * Dz);
     for (int st = 0; st < total_step; ++st) {
         ve_step_dev(B, L, c, b.xt[cur], b.tlen, b.llen, tot_all + (size_t)st * B, cur_all + (size_t)st * B, b.xt[cur ^ 1],
-                    tb_all + (size_t)st * tb_stride, rgp, dt_all);
+                    tb_all + (size_t)st * tb_stride, rgp, dt_all, z_rows, st > 0, st + 1 < total_step);
         cur ^= 1;
     }
     final_xt_ = cur;

@@ -237,8 +237,10 @@ void launch_mask_to_len(hipStream_t s, const float* mask, int B, int L, int* len
 void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, int C, int L, void* out, int ld_out = 0,
                         const int* len = nullptr, const int* row_off = nullptr /* packed destination rows */);
 // Euler update with the [B*L][D] -> [B][D][L] transpose: out[b][d][t] = t < len[b] ? prev[b][d][t] + v[(b*L+t)*D + d] * dt[b] : 0
+// z_rows (optional): the new latent also as rows [row][ldz] in `z_dtype` (columns < D only; the K padding beyond stays as the caller zeroed it) — what
+// launch_ncl_to_rows(out) would write, so that the next step's input projection needs no such launch
 void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out,
-                      const int* row_off = nullptr /* v in packed rows */);
+                      const int* row_off = nullptr /* v in packed rows */, void* z_rows = nullptr, int z_dtype = 0, int ldz = 0);
 // fp32 -> act dtype copy (n elements)
 void launch_cast(hipStream_t s, int out_dtype, const float* in, int64_t n, void* out);
 // x[b*L+t][c] += v[b*ldv + c] for t < len[b]

@@ -12,6 +12,7 @@
 #include "kernels_fold.hpp"
 
 #include <hip/hip_bf16.h>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -841,10 +842,13 @@ void launch_ncl_to_rows(hipStream_t s, int out_dtype, const float* in, int B, in
     else STN_KLAUNCH(ncl_to_rows_kernel<float>, grid, dim3(256), 0, s, in, C, L, ldo, n, static_cast<float*>(out), len, row_off);
 }
 
-// 32 x 32 LDS tile transpose: reads of v are coalesced along d, writes of out along t
+// 32 x 32 LDS tile transpose: reads of v are coalesced along d, writes of out along t.  ZT != void: the new latent is ALSO written as the rows the
+// next step's input projection reads (z[row][d], row stride ldz, the activation format — what launch_ncl_to_rows would make of `out`, bit for bit), through
+// a second transpose of the tile: the step after this one starts without that launch (its strided reads cost 11 us for 6 MB).
+template <typename ZT>
 __global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict__ prev, const float* __restrict__ v,
                                                         const float* __restrict__ dt, const int* __restrict__ len, int D, int L,
-                                                        float* __restrict__ out, const int* __restrict__ row_off) {
+                                                        float* __restrict__ out, const int* __restrict__ row_off, ZT* __restrict__ z, int ldz) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -858,20 +862,38 @@ __global__ __launch_bounds__(256) void euler_ncl_kernel(const float* __restrict_
     }
     __syncthreads();
     const float scale = dt[b];
+    float nv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int d = d0 + ty + 8 * k, t = t0 + tx;
+        nv[k] = 0.f;
         if (d < D && t < L) {
             const int64_t o = ((int64_t)b * D + d) * L + t;
-            out[o] = t < n ? prev[o] + tile[tx][ty + 8 * k] * scale : 0.f;
+            nv[k] = t < n ? prev[o] + tile[tx][ty + 8 * k] * scale : 0.f;
+            out[o] = nv[k];
+        }
+    }
+    if constexpr (!std::is_same<ZT, void>::value) {
+        __syncthreads();  // every read of the velocity tile is done
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = nv[k];  // [d][t]
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + ty + 8 * k, d = d0 + tx;
+            if (t < vrows && d < D) store1(z + (vrow0 + t) * ldz + d, tile[tx][ty + 8 * k]);
         }
     }
 }
 void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const float* dt, const int* len, int B, int D, int L, float* out,
-                      const int* row_off) {
+                      const int* row_off, void* z_rows, int z_dtype, int ldz) {
     if (B * D * L == 0) return;
     if (row_off && !len) { throw std::invalid_argument("packed euler_ncl needs lengths"); }
-    STN_KLAUNCH(euler_ncl_kernel, dim3((L + 31) / 32, (D + 31) / 32, B), dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off);
+    const dim3 grid((L + 31) / 32, (D + 31) / 32, B);
+    if (!z_rows) STN_KLAUNCH(euler_ncl_kernel<void>, grid, dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off, static_cast<void*>(nullptr), 0);
+    else if (z_dtype == F16) STN_KLAUNCH(euler_ncl_kernel<f16_t>, grid, dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off, static_cast<f16_t*>(z_rows), ldz);
+    else if (z_dtype == BF16) STN_KLAUNCH(euler_ncl_kernel<uint16_t>, grid, dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off, static_cast<uint16_t*>(z_rows), ldz);
+    else STN_KLAUNCH(euler_ncl_kernel<float>, grid, dim3(256), 0, s, prev, v, dt, len, D, L, out, row_off, static_cast<float*>(z_rows), ldz);
 }
 
 // row_off[b] = sum of len[0..b) (row_off[B] = total), row_b[row_off[b] + t] = b: the packed-row bookkeeping, one block
