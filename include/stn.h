@@ -235,6 +235,10 @@ int stn_profile_get(stn_handle* h, int idx, char* name, size_t name_cap, double*
    and returns how many workgroups that launch had. */
 int stn_dbg_xattn_hs_enable(stn_handle* h, int on);
 int64_t stn_dbg_xattn_hs_stamps(stn_handle* h, unsigned long long* out, size_t cap);
+/* diagnostics (no device needed): the run length — frames per workgroup, 0 = the default of 32 — the estimator's fold + conv + LayerNorm kernel takes for a
+   batch of these latent lengths on a device of `n_cu` compute units (one 1024-thread workgroup fills a CU: the grid is kept within ONE round of workgroups
+   where a run of 40 or 48 frames achieves that; the results do not depend on the choice).  < 0: STN_ERR_INVALID. */
+int stn_dbg_fold_run_frames(const int32_t* latent_lengths, int B, int n_cu);
 
 /* ---- op-level entry points used by the kernel parity tests (host pointers) -------------------------- */
 int stn_op_gemm(stn_handle* h, int dtype, int M, int N, int K, const float* A /*[M,K]*/, const float* W /*[N,K]*/,

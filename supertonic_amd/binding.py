@@ -154,6 +154,8 @@ def load():
     L.stn_dbg_xattn_hs_enable.argtypes = [vp, ci]
     L.stn_dbg_xattn_hs_stamps.argtypes = [vp, vp, ctypes.c_size_t]
     L.stn_dbg_xattn_hs_stamps.restype = ctypes.c_int64
+    L.stn_dbg_fold_run_frames.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.stn_dbg_fold_run_frames.restype = ctypes.c_int
     L.stn_launch_log.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     L.stn_launch_log.restype = ctypes.c_int64
     L.stn_profile_enable.argtypes = [vp, ci]
@@ -259,6 +261,15 @@ class Group:
         rows, samples = np.zeros(self.n, np.int32), np.zeros(self.n, np.int64)
         self._ck(self._lib.stn_group_last_shards(self._g, rows, samples))
         return rows, samples
+
+
+def fold_run_frames(latent_lengths, n_cu=256):
+    """frames per workgroup of the estimator's fold kernel for these latent lengths (0 = the default 32); host-only"""
+    a = np.ascontiguousarray(latent_lengths, dtype=np.int32)
+    r = load().stn_dbg_fold_run_frames(a.ctypes.data, len(a), int(n_cu))
+    if r < 0:
+        raise StnError(r, "stn_dbg_fold_run_frames: bad arguments")
+    return int(r)
 
 
 def _c(a, dt):

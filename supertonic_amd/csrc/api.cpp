@@ -350,6 +350,10 @@ int64_t stn_launch_log(stn_handle* h, char* out, size_t cap) {
     } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_STATE; }
 }
 int stn_dbg_xattn_hs_enable(stn_handle* h, int on) { STN_TRY(h, { h->eng->hs_stamps_enable(on != 0); }) }
+int stn_dbg_fold_run_frames(const int32_t* latent_lengths, int B, int n_cu) {
+    if (!latent_lengths || B < 1 || n_cu < 1) return STN_ERR_INVALID;
+    return stn::fold_run_frames(latent_lengths, B, n_cu);
+}
 int64_t stn_dbg_xattn_hs_stamps(stn_handle* h, unsigned long long* out, size_t cap) {
     if (!h) return STN_ERR_INVALID;
     try { return h->eng->hs_stamps_fetch(out, cap); } catch (const std::exception& e) { h->err = e.what(); return STN_ERR_STATE; }
