@@ -100,6 +100,32 @@ def test_synthesize_predicted_durations_and_device_noise(eng_tiny, ref_tiny):
     parity_check("tiny.e2e_wav_device_noise", eng_tiny.mode, wav, ref_wav, "e2e")
 
 
+def test_resident_steps_equal_the_staged_calls_bit_for_bit(eng_tiny):
+    """The resident pipeline keeps the latent as rows across the Euler steps (the update of step s writes the rows step s + 1 projects: no
+    [B][D][L] -> rows conversion per step); the staged call (the former vector-estimator Run site) converts on entry every time.  On padded rows
+    both take the same kernel forms, so total_step staged calls from the same noise must give the resident run's latent to the bit."""
+    a = tiny_arch()
+    ids, mask, sttl, sdp = make_inputs(a, 3, 14, [14, 9, 5])
+    durs = np.array([0.9, 0.5, 0.3], np.float32)
+    eng_tiny.set_packed_rows(False)
+    try:
+        eng_tiny.batch_upload(ids, mask, sttl, sdp, duration_override=durs)
+        eng_tiny.batch_run(4, 1.0, 77)                       # device noise from the seed; shapes from the durations
+        lat = eng_tiny.batch_fetch_latent()
+        B, D, L = lat.shape
+        _D, Lg, lat_len = host_ref.latent_geometry(durs, a.sample_rate, a.base_chunk_size, a.chunk_compress_factor, a.latent_dim)
+        assert Lg == L
+        lmask = host_ref.length_to_mask(lat_len, L)
+        noise = eng_tiny.op_randn(77, B, D, L, np.arange(B), np.asarray(lat_len, np.int32))
+        emb = eng_tiny.text_enc(ids, sttl, mask)
+        x = noise
+        for st in range(4):
+            x = eng_tiny.vector_est(x, emb, sttl, mask, lmask, np.full(B, 4, np.float32), np.full(B, st, np.float32))
+        assert np.array_equal(x, lat)
+    finally:
+        eng_tiny.set_packed_rows(True)
+
+
 def test_sharding_invariance(eng_tiny):
     """An utterance synthesized alone (as on another GPU rank) equals the same utterance inside a batch:
     noise is keyed by utterance id, masked stages ignore batch mates.  The vocoder is unmasked in the
