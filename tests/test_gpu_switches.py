@@ -116,3 +116,38 @@ def test_every_environment_switch_against_the_default(tmp_path):
                 scale = float(np.max(np.abs(w0))) + 1e-12
                 mx = float(np.max(np.abs(w0.astype(np.float64) - w1))) / scale
                 assert mx < bounds[dt], (name, val, dt, mx)
+
+
+C3_CHILD = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from supertonic_amd import binding, host, workload
+from supertonic_amd.arch import default_arch
+a = default_arch()
+n = 128
+texts = workload.utterances(n, 10, seed=1234)
+ids, mask = host.UnicodeProcessor(host.synthetic_indexer())(texts, ["en"] * n)
+sttl, sdp = workload.synthetic_styles(a, np.arange(n))
+eng = binding.Engine(0, "bf16")
+eng.load_synthetic(a, 7)
+w, d = eng.synthesize(ids, mask, sttl, sdp, 2, 1.05, duration_override=workload.forced_durations(texts), noise_seed=5)
+lat = (np.ceil(d * a.sample_rate / (a.base_chunk_size * a.chunk_compress_factor))).astype(np.int32)
+print("RESULT", hashlib.sha256(w.tobytes()).hexdigest(), binding.fold_run_frames(lat, 256), int(lat.max()))
+"""
+
+
+def test_the_bench_shape_is_bit_identical_under_every_fold_run_length(tmp_path):
+    """At the bench's shape (128 ten-word utterances) the fold kernel's run length is chosen from the lengths (40 frames: one round of workgroups,
+    tests/test_fold_run_cpu.py); the waveform must not depend on it: the default against runs of 32 and of 48 frames forced."""
+    out = {}
+    for tag, extra in (("auto", {}), ("32", {"STN_DEV_SWITCHES": "1", "STN_FOLD_TCH": "32"}), ("48", {"STN_DEV_SWITCHES": "1", "STN_FOLD_TCH": "48"})):
+        env = dict(os.environ)
+        for k in ("STN_DEV_SWITCHES", "STN_FOLD_TCH"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", C3_CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stdout[-2000:], r.stderr[-4000:])
+        out[tag] = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")][-1]
+    assert out["auto"][2] == "40" and int(out["auto"][3]) > 64          # (the choice this test is about)
+    assert out["auto"][1] == out["32"][1] == out["48"][1]
