@@ -160,9 +160,9 @@ int stn_set_fused_xattn(stn_handle* h, int on);
  * K4-split (see stn_set_fused_ffn_min_rows); 0 = never.  The default (9) is the set of stages where a form measured faster on
  * MI355X.
  * WHAT IS AND IS NOT BIT-IDENTICAL.  Which kernel a block runs is decided by the launch's row count (these thresholds; the K4-split of
- * the estimator's blocks is 12 ways up to 2048 packed rows and 4 ways beyond; also split-K for small exact-fp32 GEMMs and the attention
+ * the estimator's blocks is 12 ways up to 1536 packed rows, 8 ways up to 4096 and 4 ways beyond; also split-K for small exact-fp32 GEMMs and the attention
  * grid shape), so an utterance synthesized alone, a small shard of a batch (e.g. 16 utterances per GPU of a strong-scaling run: below
- * 2048 rows) and the same utterance inside a large batch may run different kernels: they agree to rounding (K4 vs two launches: fp32 summation order and, in f16, the exp2- vs
+ * 1536 rows) and the same utterance inside a large batch may run different kernels: they agree to rounding (K4 vs two launches: fp32 summation order and, in f16, the exp2- vs
  * erf-form GELU; K4-split: 16-bit partial sums), with identical predicted durations to 1e-5 and identical latent lengths
  * (tests/test_gpu_batch_invariance.py holds recorded bounds).  Within one kernel regime a row's result does not depend on the
  * number of rows, their order or their position in the launch: packed vs trimmed vs dense vocoder rows, graph replay vs eager and

@@ -427,7 +427,7 @@ int stn_op_ffn_bench(stn_handle* h, int M, int C, int I, int fused, int iters, d
 int stn_op_fold_dwconv_ln(stn_handle* h, int B, int C, int k, int dil, int S, const int32_t* seqlen, const float* x, const float* part,
                           const float* b2, const float* gamma, const float* rowvec, const float* w, const float* bias, const float* g,
                           const float* b, float* x_out, float* y) {
-    STN_TRY(h, { need(B > 0 && C > 0 && C % 8 == 0 && (k == 5 || k == 7) && dil > 0 && (S == 4 || S == 12 || S == 24) && seqlen && x && part && w && bias && g && b && x_out && y,
+    STN_TRY(h, { need(B > 0 && C > 0 && C % 8 == 0 && (k == 5 || k == 7) && dil > 0 && (S == 4 || S == 8 || S == 12 || S == 24) && seqlen && x && part && w && bias && g && b && x_out && y,
                       "stn_op_fold_dwconv_ln: bad argument");
                  int64_t tot = 0;
                  for (int i = 0; i < B; ++i) { need(seqlen[i] >= 0 && seqlen[i] < (1 << 20), "stn_op_fold_dwconv_ln: seqlen out of range"); tot += seqlen[i]; }

@@ -1017,7 +1017,7 @@ void Engine::prepare_ffn_weights() {
         sync();  // tmp is reused by the next block
         FfnW fw; fw.wseq = wseq;
         if (p.compare(0, 3, "ve.") == 0)  // the estimator's blocks also as hidden-split stage streams, one copy per split
-            for (int S : {4, 12}) {  // (the splits ffn_split_choose hands out)
+            for (int S : {4, 8, 12}) {  // (the splits ffn_split_choose hands out)
                 if (!ffn_split_valid(dt_, C, hid, S)) continue;
                 void* ws = nullptr;
                 STN_HIP(hipMalloc(&ws, (size_t)2 * hid * C * 2));

@@ -131,8 +131,8 @@ class Engine {
     std::unordered_map<const void*, const void*> frag_acc_w_;  // ... -> its copy in accumulator-operand k order (Wo of the head-split block, kernels_xattn_hs.hip)
     void prepare_vocoder_constants();     // zero-latent response of the loaded model: quiet chunk and edge tail
     void prepare_ffn_weights();           // fragment-ordered copies of every ConvNeXt block's pw1 / pw2 (kernels_ffn.hip, K4)
-    struct FfnW { const void* wseq = nullptr; const void* wsplit[3] = {nullptr, nullptr, nullptr}; };  // wsplit: the hidden-split stage streams for S = 4, 12, 24
-    static int split_slot(int S) { return S == 4 ? 0 : S == 12 ? 1 : 2; }
+    struct FfnW { const void* wseq = nullptr; const void* wsplit[4] = {nullptr, nullptr, nullptr, nullptr}; };  // wsplit: the hidden-split stage streams for S = 4, 12, 24, 8
+    static int split_slot(int S) { return S == 4 ? 0 : S == 12 ? 1 : S == 24 ? 2 : 3; }
     std::unordered_map<const void*, FfnW> ffn_w_;  // key: the block's row-major 16-bit pw1 matrix
 
     // ---- host-pointer stages: 1:1 with the reference's four Run sites ------------------------------

@@ -134,11 +134,11 @@ struct FfnArgs {
 bool ffn_fused_supported(int dtype, int C, int I);
 // whether the block shape has a K4-split form at all (0: no; > 1: yes)
 int ffn_split_factor(int dtype, int C, int I);
-// splits a block shape can run with (4, 12, 24: I / 32 / S hidden tiles per workgroup, an even number), and the one a launch of M rows
-// takes: 12 ways up to 16 slabs (2048 rows), 4 ways beyond.  The split is a function of the launch's ROW COUNT, so the order in which a
+// splits a block shape can run with (4, 8, 12, 24: I / 32 / S hidden tiles per workgroup, an even number), and the one a launch of M rows
+// takes: 12 ways up to 12 slabs (1536 rows), 8 ways up to 32 slabs (4096 rows: still one round of workgroups), 4 ways beyond.  The split is a function of the launch's ROW COUNT, so the order in which a
 // row's 16-bit partial sums are added depends on how many rows the launch has: results on either side of the boundary (an utterance
 // alone, a 16-utterance shard of a strong-scaling run, the unsharded batch) agree to rounding, not bit for bit (include/stn.h,
-// tests/test_gpu_ffn.py::test_ffn_split_regimes_agree_to_rounding: 2 048 rows against 2 176)
+// tests/test_gpu_ffn.py::test_ffn_split_regimes_agree_to_rounding: 1 536, 1 664 and 4 224 rows)
 bool ffn_split_valid(int dtype, int C, int I, int S);
 int ffn_split_choose(int dtype, int C, int I, int64_t M);
 inline int64_t ffn_split_rows(int64_t M) { return (M + 127) / 128 * 128; }

@@ -280,7 +280,7 @@ int ffn_split_factor(int dtype, int C, int I) {
     return 4;
 }
 bool ffn_split_valid(int dtype, int C, int I, int S) {
-    return ffn_split_factor(dtype, C, I) > 1 && (S == 4 || S == 12 || S == 24) && (I / 32) % (2 * S) == 0;
+    return ffn_split_factor(dtype, C, I) > 1 && (S == 4 || S == 8 || S == 12 || S == 24) && (I / 32) % (2 * S) == 0;
 }
 // Few rows: more, shorter workgroups per slab (each still streams only ITS share of the weights, so the cost of a launch is one
 // workgroup's prologue + its T = I/32/S hidden tiles + epilogue, whatever the number of slabs).  Measured on B sequences of 58 frames
@@ -294,7 +294,10 @@ int ffn_split_choose(int dtype, int C, int I, int64_t M) {
     if (ffn_split_factor(dtype, C, I) < 2) return 0;
     static const int force = [] { const char* e = stn::dev_env("STN_FFN_SPLIT_S"); return e ? atoi(e) : 0; }();  // A/B switch
     const int64_t nslab = (M + 127) / 128;
-    const int want = force ? force : nslab <= 16 ? 12 : 4;
+    // round 4 (profiles/r04_ffn_split_mid_m.txt, block = fold_dwconv_ln + K4-split, us): 8 ways fill the chip where 4 ways leave half of it idle —
+    // 48 sequences 26.9 against 29.5 (4 ways) and 34.4 (12 ways: two rounds), 64 sequences 28.5 / 30.9 / 37.4, 32 sequences 25.4 / 28.0 / 26.1; from 96
+    // sequences on 8 ways are two rounds (41.8 against 33.5) and 4 ways stay
+    const int want = force ? force : nslab <= 12 ? 12 : nslab <= 32 ? 8 : 4;
     return ffn_split_valid(dtype, C, I, want) ? want : 4;
 }
 
@@ -340,7 +343,7 @@ void launch_ffn_fused(hipStream_t s, int dtype, int C, const FfnArgs& a) {
     if (!ffn_fused_supported(dtype, C, a.I)) throw std::invalid_argument("launch_ffn_fused: unsupported shape or dtype");
     if (a.split > 1 && (!ffn_split_valid(dtype, C, a.I, a.split) || !a.part || a.part_stride < ffn_split_rows(a.M) * C ||
                         (reinterpret_cast<uintptr_t>(a.part) & 15)))
-        throw std::invalid_argument("launch_ffn_fused: hidden split needs a valid split (4, 12 or 24 dividing I / 64) and a 16-byte aligned part buffer of [split][rows padded to 128][C]");
+        throw std::invalid_argument("launch_ffn_fused: hidden split needs a valid split (4, 8, 12 or 24 dividing I / 64) and a 16-byte aligned part buffer of [split][rows padded to 128][C]");
     if (a.split <= 1 && a.part) throw std::invalid_argument("launch_ffn_fused: part without split");
     if ((size_t)a.M * a.ldx * 2 >= 0x7FFFFFFFull || a.ldx % 8 || (reinterpret_cast<uintptr_t>(a.xn) & 15) ||
         (a.split <= 1 && (a.ldo % 4 || !a.x || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.rowvec && (a.rv_ld % 4 || (reinterpret_cast<uintptr_t>(a.rowvec) & 15))))))

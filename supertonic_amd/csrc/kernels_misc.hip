@@ -498,9 +498,9 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(float* __restrict__ x, int
 }
 
 static void check_fold_args(const FoldArgs& f, int64_t M, int C, const char* who) {
-    if (!f.part || (f.S != 4 && f.S != 12 && f.S != 24) || f.part_stride < M * C || !f.b2 || !f.gamma || (f.rowvec && f.rv_ld % 4) || (reinterpret_cast<uintptr_t>(f.part) & 15) ||
+    if (!f.part || (f.S != 4 && f.S != 8 && f.S != 12 && f.S != 24) || f.part_stride < M * C || !f.b2 || !f.gamma || (f.rowvec && f.rv_ld % 4) || (reinterpret_cast<uintptr_t>(f.part) & 15) ||
         (reinterpret_cast<uintptr_t>(f.b2) & 15) || (reinterpret_cast<uintptr_t>(f.gamma) & 15) || (f.rowvec && (reinterpret_cast<uintptr_t>(f.rowvec) & 15)))
-        throw std::invalid_argument(std::string(who) + ": needs 16-byte aligned partial sums of 4, 12 or 24 splits, b2 and gamma");
+        throw std::invalid_argument(std::string(who) + ": needs 16-byte aligned partial sums of 4, 8, 12 or 24 splits, b2 and gamma");
 }
 
 void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, const FoldArgs& f, const float* g, const float* b, float eps, void* y) {
@@ -512,7 +512,7 @@ void launch_fold_ln(hipStream_t s, int act_dtype, float* x, int64_t M, int C, co
     const uint16_t* P = static_cast<const uint16_t*>(f.part);
 #define STN_FOLD_LN(OUT, F16_, RV_, S_) STN_KLAUNCH((fold_ln_kernel<OUT, F16_, RV_, S_>), grid, dim3(256), 0, s, x, M, C, P, f.part_stride, f.b2, f.gamma, f.rowvec, \
                                                     f.rv_ld, f.row_b, g, b, eps, static_cast<OUT*>(y))
-#define STN_FOLD_LN_S(OUT, F16_, RV_) do { if (f.S == 4) STN_FOLD_LN(OUT, F16_, RV_, 4); else if (f.S == 12) STN_FOLD_LN(OUT, F16_, RV_, 12); else STN_FOLD_LN(OUT, F16_, RV_, 24); } while (0)
+#define STN_FOLD_LN_S(OUT, F16_, RV_) do { if (f.S == 4) STN_FOLD_LN(OUT, F16_, RV_, 4); else if (f.S == 8) STN_FOLD_LN(OUT, F16_, RV_, 8); else if (f.S == 12) STN_FOLD_LN(OUT, F16_, RV_, 12); else STN_FOLD_LN(OUT, F16_, RV_, 24); } while (0)
     if (act_dtype == F16) { if (f.rowvec) STN_FOLD_LN_S(f16_t, true, true); else STN_FOLD_LN_S(f16_t, true, false); }
     else { if (f.rowvec) STN_FOLD_LN_S(uint16_t, false, true); else STN_FOLD_LN_S(uint16_t, false, false); }
 #undef STN_FOLD_LN_S
@@ -754,6 +754,7 @@ template <typename OutT, bool F16, int K, bool RV, int NSLOT>
 static void launch_fold_dwconv_ln_t2(hipStream_t s, const float* x_in, float* x_out, int B, int L, int C, const FoldArgs& f, const float* w_t,
                                      const float* bias, int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen, const int* row_off) {
     if (f.S == 4) launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 4>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
+    else if (f.S == 8) launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 8>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     else if (f.S == 12) launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 12>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
     else launch_fold_dwconv_ln_t3<OutT, F16, K, RV, NSLOT, 24>(s, x_in, x_out, B, L, C, f, w_t, bias, dil, g, b, eps, y, seqlen, row_off);
 }

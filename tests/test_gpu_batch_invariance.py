@@ -1,5 +1,5 @@
 """An utterance alone vs the same utterance inside a full-size batch: the engine picks kernels by launch
-size — K4 for the vocoder from 18 432 rows, K4-split for the estimator 12 ways up to 2 048 rows and 4 ways beyond, one or two utterances
+size — K4 for the vocoder from 18 432 rows, K4-split for the estimator 12 ways up to 1 536 rows, 8 ways up to 4 096 and 4 ways beyond, one or two utterances
 per workgroup in the head-split cross-attention, split-K for small exact-fp32 GEMMs, a wider attention grid below 96 workgroups — so
 the two syntheses run DIFFERENT kernels.  What the ABI promises across those thresholds is
 equality to rounding (recorded bounds below, relative to the rms of the waveform), identical predicted durations to 1e-5 and hence

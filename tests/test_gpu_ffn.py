@@ -166,14 +166,14 @@ def ref64_split(xn, W1, b1, W2, b2, gamma, x, rowvec, row_b, S=4, rnd=bf16_round
     return out
 
 
-@pytest.mark.parametrize("M,nseq", [(7436, 128), (1000, 0), (129, 0), (31, 3)])
+@pytest.mark.parametrize("M,nseq", [(7436, 128), (3000, 50), (1000, 0), (129, 0), (31, 3)])
 def test_ffn_split_vs_float64_and_two_launches(eng, M, nseq):
     C, I = 384, 1536
     ops = make(M, C, I, 7 * M + 1, nseq)
     got = eng.op_ffn(*ops[:7], rowvec=ops[7], row_b=ops[8], fused=2)
     assert np.all(np.isfinite(got))
     x = ops[6]
-    S = 12 if (M + 127) // 128 <= 16 else 4  # ffn_split_choose
+    S = 12 if (M + 127) // 128 <= 12 else 8 if (M + 127) // 128 <= 32 else 4  # ffn_split_choose
     mx, rms = rel_err(got - x, ref64_split(*ops, S=S) - x)
     assert rms < 3e-3 and mx < 3e-2, (mx, rms)
     # against the unsplit float64 reference and the two launches: the 16-bit partial sums add ~2^-9 of a quarter's contribution
@@ -185,8 +185,8 @@ def test_ffn_split_vs_float64_and_two_launches(eng, M, nseq):
 
 
 def test_ffn_split_rows_do_not_depend_on_position_or_row_count(eng):
-    """Within one split regime (here 12 ways: up to 16 slabs of 128 rows) a row gives the same bits alone, in another slab, in another
-    launch size; across the boundary (4 ways from 17 slabs on) the results agree to rounding (next test)."""
+    """Within one split regime (here 12 ways: up to 12 slabs of 128 rows) a row gives the same bits alone, in another slab, in another
+    launch size; across the boundaries (8 ways from 13 slabs on, 4 ways from 33) the results agree to rounding (next test)."""
     M, C, I = 700, 384, 1536
     ops = make(M, C, I, 9)
     full = eng.op_ffn(*ops[:7], fused=2)
@@ -195,19 +195,25 @@ def test_ffn_split_rows_do_not_depend_on_position_or_row_count(eng):
     assert np.array_equal(full[sel], part)
     one = eng.op_ffn(ops[0][5:6], *ops[1:6], ops[6][5:6], fused=2)
     assert np.array_equal(full[5:6], one)
+    # ... and within the 8-way regime (13 .. 32 slabs)
+    M = 3000
+    ops = make(M, C, I, 10)
+    full = eng.op_ffn(*ops[:7], fused=2)
+    part = eng.op_ffn(ops[0][:2000], *ops[1:6], ops[6][:2000], fused=2)
+    assert np.array_equal(full[:2000], part)
 
 
 def test_ffn_split_regimes_agree_to_rounding(eng):
-    """2 048 rows run 12 ways, 2 176 rows 4 ways: the shared rows differ only by the rounding of the 16-bit partial sums."""
+    """1 536 rows run 12 ways, 1 664 rows 8 ways, 4 224 rows 4 ways: the shared rows differ only by the rounding of the 16-bit partial sums."""
     C, I = 384, 1536
-    ops = make(2176, C, I, 11)
-    big = eng.op_ffn(*ops[:7], fused=2)
-    small = eng.op_ffn(ops[0][:2048], *ops[1:6], ops[6][:2048], fused=2)
-    x = ops[6][:2048]
-    assert not np.array_equal(big[:2048], small)
-    mx, rms = rel_err(big[:2048] - x, small - x)
-    assert rms < 4e-3 and mx < 4e-2, (mx, rms)
-    for got, n in ((big, 2176), (small, 2048)):
+    ops = make(4224, C, I, 11)
+    runs = {n: eng.op_ffn(ops[0][:n], *ops[1:6], ops[6][:n], fused=2) for n in (1536, 1664, 4224)}
+    x = ops[6][:1536]
+    for a, b in ((1536, 1664), (1664, 4224), (1536, 4224)):
+        assert not np.array_equal(runs[a][:1536], runs[b][:1536])
+        mx, rms = rel_err(runs[a][:1536] - x, runs[b][:1536] - x)
+        assert rms < 4e-3 and mx < 4e-2, (a, b, mx, rms)
+    for n, got in runs.items():
         sub = (ops[0][:n], *ops[1:6], ops[6][:n], None, None)
         mx, rms = rel_err(got - ops[6][:n], ref64(*sub) - ops[6][:n])
         assert rms < 6e-3 and mx < 5e-2, (n, mx, rms)
@@ -248,7 +254,7 @@ def _fold_dwconv_ref(seqlen, x, part16, b2, gamma, rowvec, w, bias, g, b, k, dil
     return xo, out
 
 
-@pytest.mark.parametrize("k,dil,C,S", [(5, 1, 384, 4), (5, 2, 384, 4), (5, 4, 384, 12), (5, 8, 384, 4), (7, 2, 512, 4), (5, 8, 96, 12), (5, 1, 384, 24)])
+@pytest.mark.parametrize("k,dil,C,S", [(5, 1, 384, 4), (5, 2, 384, 4), (5, 4, 384, 12), (5, 8, 384, 4), (7, 2, 512, 4), (5, 8, 96, 12), (5, 1, 384, 24), (5, 2, 384, 8)])
 def test_fold_dwconv_ln_vs_numpy(eng, k, dil, C, S):
     rng = np.random.default_rng(100 * k + dil + C)
     seqlen = np.array([1, 5, 33, 64, 70, 150, 2, 31, 32, 96, 97], np.int32)

@@ -48,6 +48,7 @@ SWITCHES = [
     ("STN_FFN", "0", "bound"),             # every pointwise pair as two GEMM launches
     ("STN_FFN", "1", "bound"),             # K4 without the hidden split
     ("STN_FFN_SPLIT_S", "4", "bound"),     # the 4-way split at every size
+    ("STN_FFN_SPLIT_S", "8", "bound"),     # the 8-way split at every size
     ("STN_FFN_SPLIT_MIN_ROWS", "100000", "bound"),
     ("STN_FFN_MIN_ROWS", "1", "bound"),    # vocoder K4 at every size
     ("STN_GEMM_TR", "0", "bound"),

@@ -13,7 +13,7 @@ if what == "splitvar":  # one line for the timing-variants build (STN_LIB=build/
     best = min(f, key=lambda r: r["ms"])
     print(f"var={os.environ.get('STN_FFN_VAR', '0')} ve M=7436 K4-split {best['ms']*1e3:7.1f} us cycles/wg: first={best['first_stage']:.0f} loop={best['tile_loop']:.0f} epi={best['epilogue']:.0f}", flush=True)
     sys.exit(0)
-if what == "splitm":  # few rows: which split pays (STN_DEV_SWITCHES=1 STN_FFN_SPLIT_S=<4|12|24> forces one; unset: ffn_split_choose)
+if what == "splitm":  # few rows: which split pays (STN_DEV_SWITCHES=1 STN_FFN_SPLIT_S=<4|8|12|24> forces one; unset: ffn_split_choose)
     tag = os.environ.get("STN_FFN_SPLIT_S", "auto")
     for B in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128):
         a = min((eng.op_block_bench(B, 58, 384, 1536, 5, 2, 0, iters) for _ in range(2)), key=lambda r: r["ms"])
