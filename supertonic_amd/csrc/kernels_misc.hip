@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_v2_kernel(const float* __restri
 // of the vocoder's k=7 blocks by 4x at R=8 (HBM already saw each frame once; the re-reads were L2 bandwidth).
 // ---------------------------------------------------------------------------------------------
 template <typename OutT, int K, int R>
-__global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restrict__ x, int nseq, int L, int C,
+__device__ __forceinline__ void dwconv_ln_v3_body(const float* __restrict__ x, int nseq, int L, int C,
                                                            const float* __restrict__ w_t, const float* __restrict__ bias,
                                                            int dil, int wps /*waves per sequence*/, const float* __restrict__ g,
                                                            const float* __restrict__ bt, float eps, OutT* __restrict__ y,
@@ -335,12 +335,33 @@ __global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restri
 }
 
 template <typename OutT, int K, int R>
+__global__ __launch_bounds__(256) void dwconv_ln_v3_kernel(const float* __restrict__ x, int nseq, int L, int C, const float* __restrict__ w_t,
+                                                           const float* __restrict__ bias, int dil, int wps, const float* __restrict__ g, const float* __restrict__ bt,
+                                                           float eps, OutT* __restrict__ y, const int* __restrict__ seqlen, const int* __restrict__ row_off, int xcd_runs) {
+    dwconv_ln_v3_body<OutT, K, R>(x, nseq, L, C, w_t, bias, dil, wps, g, bt, eps, y, seqlen, row_off, xcd_runs);
+}
+// the same body held to 128 VGPRs (four waves per SIMD instead of three: the vocoder's k = 7 combs of four need 130 by themselves)
+template <typename OutT, int K, int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void dwconv_ln_v3_occ4_kernel(
+    const float* __restrict__ x, int nseq, int L, int C, const float* __restrict__ w_t, const float* __restrict__ bias, int dil, int wps,
+    const float* __restrict__ g, const float* __restrict__ bt, float eps, OutT* __restrict__ y, const int* __restrict__ seqlen,
+    const int* __restrict__ row_off, int xcd_runs) {
+    dwconv_ln_v3_body<OutT, K, R>(x, nseq, L, C, w_t, bias, dil, wps, g, bt, eps, y, seqlen, row_off, xcd_runs);
+}
+
+template <typename OutT, int K, int R>
 static void launch_dwconv_ln_v3_kr(hipStream_t s, const float* x, int nseq, int L, int C, const float* w_t, const float* bias,
                                    int dil, const float* g, const float* b, float eps, OutT* y, const int* seqlen,
                                    const int* row_off = nullptr) {
     const int wps = ((L + R * dil - 1) / (R * dil)) * dil;
     const int64_t nw = (int64_t)nseq * wps;
     static const int xcd_runs = [] { const char* e = stn::dev_env("STN_DWCONV_XCD"); return e ? atoi(e) : 1; }();  // A/B switch
+    // k = 7 combs of four (the vocoder at batch size): 130 VGPRs are three waves per SIMD, 127 are four — 42.5 -> 38.2 us per launch.  (The IEEE-half
+    // instantiation needs 184 and would spill: it keeps the plain kernel.)
+    if (K == 7 && R == 4 && !std::is_same<OutT, f16_t>::value)
+        STN_KLAUNCH((dwconv_ln_v3_occ4_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
+                           dil, wps, g, b, eps, y, seqlen, row_off, xcd_runs);
+    else
     STN_KLAUNCH((dwconv_ln_v3_kernel<OutT, K, R>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, x, nseq, L, C, w_t, bias,
                        dil, wps, g, b, eps, y, seqlen, row_off, xcd_runs);
 }
