@@ -921,20 +921,29 @@ void launch_euler_ncl(hipStream_t s, const float* prev, const float* v, const fl
 // row_off[b] = sum of len[0..b) (row_off[B] = total), row_b[row_off[b] + t] = b: the packed-row bookkeeping, one block
 __global__ void row_map_kernel(const int* __restrict__ len, int B, int* __restrict__ row_off, int* __restrict__ row_b, int rows_padded) {
     __shared__ int off_s[1025];
-    if (threadIdx.x == 0) {
-        int a = 0;
-        for (int b = 0; b < B; ++b) { off_s[b] = a; a += len[b]; }
-        off_s[B] = a;
-    }
+    // exclusive prefix sum of up to 1024 lengths: every thread loads one, Hillis-Steele over LDS (10 steps), instead of one thread walking them
+    const int tid = threadIdx.x;
+    int v = tid < B ? len[tid] : 0;
+    off_s[tid + 1] = v;
+    if (tid == 0) off_s[0] = 0;
     __syncthreads();
-    for (int b = threadIdx.x; b <= B; b += blockDim.x) row_off[b] = off_s[b];
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int add = tid + 1 > d ? off_s[tid + 1 - d] : 0;
+        __syncthreads();
+        if (tid + 1 > d) off_s[tid + 1] += add;
+        __syncthreads();
+    }
+    for (int b = tid; b <= B; b += blockDim.x) row_off[b] = off_s[b];
     if (!row_b) return;
-    for (int b = 0; b < B; ++b) {
-        const int o = off_s[b], n = off_s[b + 1] - o;
-        for (int t = threadIdx.x; t < n; t += blockDim.x) row_b[o + t] = b;
+    // row -> sequence: every thread walks its own rows and finds the sequence by bisection over the offsets (B <= 1024: 10 steps)
+    const int total = off_s[B];
+    for (int r = tid; r < total; r += blockDim.x) {
+        int lo = 0, hi = B;  // off_s[lo] <= r < off_s[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off_s[mid] <= r) lo = mid; else hi = mid; }
+        row_b[r] = lo;
     }
     // dead rows behind the last sequence (a row count rounded up to a shape bucket): sequence 0, so that per-row lookups stay in range
-    for (int t = off_s[B] + threadIdx.x; t < rows_padded; t += blockDim.x) row_b[t] = 0;
+    for (int t = total + tid; t < rows_padded; t += blockDim.x) row_b[t] = 0;
 }
 
 // packed rows [sum len][W] -> padded [B][T][W] with zeros past each sequence's length (W % 4 == 0)
