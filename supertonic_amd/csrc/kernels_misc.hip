@@ -1072,12 +1072,15 @@ void launch_vocoder_in(hipStream_t s, const float* latent, int B, int L, int ld,
 // padding), where frame tt of the vocoder is latent position l = tt / ccf, channel block q = tt % ccf: latent[b][q * ld + ci][l].
 // A workgroup owns IM2_TF consecutive frames of one sequence: it stages the latent positions they touch in LDS ([channel][l], the reads run along l) and
 // writes whole rows of cols, consecutive lanes consecutive columns (the former one-thread-per-element form gathered 4 bytes per lane with four integer
-// divisions each: 38 us for the bench's 23 MB; this one 9).
+// divisions each: 38 us for the bench's 23 MB).
 constexpr int IM2_TF = 32;
-template <typename OutT>
-__global__ __launch_bounds__(256) void vocoder_im2col_kernel(const float* __restrict__ latent, int L, int ld, int ccf, int k, int kp,
+// FIXED: the published shape (24 latent channels x 6, k = 7, K padded to 192) as compile-time constants — the index arithmetic is three divisions per
+// element, and with run-time divisors they, not the bytes, set the kernel's time; with them and eight columns per 16-byte store 38 -> 17 us
+template <typename OutT, bool FIXED>
+__global__ __launch_bounds__(256) void vocoder_im2col_kernel(const float* __restrict__ latent, int L, int ld_, int ccf_, int k_, int kp_,
                                                              OutT* __restrict__ cols, const int* __restrict__ seqlen, const int* __restrict__ row_off) {
     extern __shared__ float im2_sm[];  // [D][NL]
+    const int ld = FIXED ? 24 : ld_, ccf = FIXED ? 6 : ccf_, k = FIXED ? 7 : k_, kp = FIXED ? 192 : kp_;
     const int T = L * ccf, D = ld * ccf, half = (k - 1) >> 1;
     const int tiles = (T + IM2_TF - 1) / IM2_TF;
     const int b = (int)blockIdx.x / tiles, t0 = ((int)blockIdx.x % tiles) * IM2_TF;
@@ -1090,14 +1093,28 @@ __global__ __launch_bounds__(256) void vocoder_im2col_kernel(const float* __rest
     }
     __syncthreads();
     const int t1 = min(t0 + IM2_TF, row_off ? n : T);
-    for (int i = threadIdx.x; i < (t1 - t0) * kp; i += 256) {
-        const int r = i / kp, col = i - r * kp, t = t0 + r;
+    const int64_t row00 = row_off ? (int64_t)row_off[b] : (int64_t)b * T;
+    auto value = [&](int t, int col) {
         float v = 0.f;
         if (col < ld * k) {
             const int ci = col / k, j = col - ci * k, tt = t + j - half;
             if (tt >= 0 && tt < n) { const int l = tt / ccf, q = tt - l * ccf; v = im2_sm[(q * ld + ci) * NL + (l - l0)]; }
         }
-        store1(cols + ((row_off ? (int64_t)row_off[b] : (int64_t)b * T) + t) * kp + col, v);
+        return v;
+    };
+    if constexpr (FIXED && sizeof(OutT) == 2) {  // eight columns per thread: one 16-byte store (kp = 192 = 24 x 8)
+        for (int i = threadIdx.x; i < (t1 - t0) * 24; i += 256) {
+            const int r = i / 24, c8 = i - r * 24, t = t0 + r;
+            OutT tmp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) store1(tmp + e, value(t, c8 * 8 + e));
+            *reinterpret_cast<uint4*>(cols + (row00 + t) * kp + c8 * 8) = *reinterpret_cast<const uint4*>(tmp);
+        }
+    } else {
+        for (int i = threadIdx.x; i < (t1 - t0) * kp; i += 256) {
+            const int r = i / kp, col = i - r * kp, t = t0 + r;
+            store1(cols + (row00 + t) * kp + col, value(t, col));
+        }
     }
 }
 void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, int B, int L, int ld, int ccf, int k, int kp, void* cols,
@@ -1108,9 +1125,13 @@ void launch_vocoder_im2col(hipStream_t s, int out_dtype, const float* latent, in
     const size_t lds = sizeof(float) * (size_t)ld * ccf * nl_max;
     if (lds > 64 * 1024 || (int64_t)B * tiles > 0x7FFFFFFFll) throw std::invalid_argument("launch_vocoder_im2col: latent window does not fit the staging buffer");
     const dim3 grid((unsigned)(B * tiles));
-    if (out_dtype == F16) STN_KLAUNCH(vocoder_im2col_kernel<f16_t>, grid, dim3(256), lds, s, latent, L, ld, ccf, k, kp, static_cast<f16_t*>(cols), seqlen, row_off);
-    else if (out_dtype == BF16) STN_KLAUNCH(vocoder_im2col_kernel<uint16_t>, grid, dim3(256), lds, s, latent, L, ld, ccf, k, kp, static_cast<uint16_t*>(cols), seqlen, row_off);
-    else STN_KLAUNCH(vocoder_im2col_kernel<float>, grid, dim3(256), lds, s, latent, L, ld, ccf, k, kp, static_cast<float*>(cols), seqlen, row_off);
+    const bool fixed = ld == 24 && ccf == 6 && k == 7 && kp == 192;
+#define STN_IM2(T_) do { if (fixed) STN_KLAUNCH((vocoder_im2col_kernel<T_, true>), grid, dim3(256), lds, s, latent, L, ld, ccf, k, kp, static_cast<T_*>(cols), seqlen, row_off); \
+                         else STN_KLAUNCH((vocoder_im2col_kernel<T_, false>), grid, dim3(256), lds, s, latent, L, ld, ccf, k, kp, static_cast<T_*>(cols), seqlen, row_off); } while (0)
+    if (out_dtype == F16) STN_IM2(f16_t);
+    else if (out_dtype == BF16) STN_IM2(uint16_t);
+    else STN_IM2(float);
+#undef STN_IM2
 }
 
 template <typename InT>
