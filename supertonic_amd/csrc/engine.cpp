@@ -173,6 +173,7 @@ Engine::~Engine() {
     for (void* p : batch_retired_) (void)hipFree(p);
     if (vo_quiet_) (void)hipFree(vo_quiet_);
     if (vo_edge_) (void)hipFree(vo_edge_);
+    if (tcond_.buf) (void)hipFree(tcond_.buf);
     for (auto& sp : spans_) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
     drop_graphs();
@@ -791,11 +792,11 @@ void Engine::ve_text_kv_dev(const VeCtx& c, int B, int Lt, const void* text_rows
 }
 
 // sinusoid(t * scale) -> Linear -> SiLU -> Linear -> per-block Linear, for `rows` independent (current, total) pairs
-float* Engine::ve_time_cond_dev(int rows, const float* total_step, const float* current_step) {
+float* Engine::ve_time_cond_dev(int rows, const float* total_step, const float* current_step, float* tb_out) {
     stage_ = "ve";
     const stn_arch& a = a_;
     const int C = a.ve_dim, nb = a.ve_main_blocks;
-    float* tb = f32_alloc((int64_t)rows * nb * C);  // stays allocated for the caller
+    float* tb = tb_out ? tb_out : f32_alloc((int64_t)rows * nb * C);  // (arena: stays allocated for the caller)
     const Arena::Mark mk = ar_.mark();
     float* te = f32_alloc((int64_t)rows * a.ve_time_dim);
     launch_time_embed(s_, current_step, total_step, rows, a.ve_time_dim, a.time_scale, te);

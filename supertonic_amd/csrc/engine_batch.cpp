@@ -204,6 +204,7 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
         pin_valid_ = true;
     }
 
+    ensure_time_cond(total_step, B);  // eager, on s_, ahead of whatever is replayed or captured below (same stream: ordered)
     GraphKey key;
     key.B = B; key.Lt = Lt; key.L = L; key.steps = total_step; key.noise = b.have_noise; key.ragged = vo_ragged_; key.xattn = fused_xattn_;
     key.ffn = fused_ffn_; key.gen = b.gen; key.wgen = wgen_; key.pin = pin_llen_;
@@ -294,6 +295,29 @@ void Engine::batch_run(int total_step, float speed, uint64_t noise_seed) {
 }
 
 // Everything after the duration read: lengths to the device, text encoder, initial latent, Euler loop, vocoder.
+void Engine::ensure_time_cond(int total_step, int B) {
+    TimeCond& t = tcond_;
+    if (t.steps == total_step && t.B == B && t.wgen == wgen_ && t.buf) return;
+    const stn_arch& a = a_;
+    const size_t n_cnt = (size_t)2 * total_step * B + (size_t)B, n_tb = (size_t)total_step * B * a.ve_main_blocks * a.ve_dim;
+    const size_t need = (n_cnt + 3) / 4 * 4 + n_tb;  // (tb 16-byte aligned behind the counters)
+    if (need > t.cap) {
+        sync();
+        drop_graphs();  // captured pipelines read the old buffer
+        if (t.buf) (void)hipFree(t.buf);
+        t.buf = nullptr; t.cap = 0;
+        STN_HIP(hipMalloc(reinterpret_cast<void**>(&t.buf), need * sizeof(float)));
+        t.cap = need;
+    }
+    t.tot = t.buf; t.cur = t.tot + (size_t)total_step * B; t.dt = t.cur + (size_t)total_step * B; t.tb = t.buf + (n_cnt + 3) / 4 * 4;
+    t.steps = 0;  // (invalid until the launches below are enqueued)
+    const Arena::Mark mk = ar_.mark();
+    launch_step_counters(s_, t.tot, t.cur, t.dt, B, total_step);
+    (void)ve_time_cond_dev(total_step * B, t.tot, t.cur, t.tb);
+    ar_.release(mk);
+    t.steps = total_step; t.B = B; t.wgen = wgen_;
+}
+
 void Engine::enqueue_after_duration(int total_step, const std::function<void()>& take_text_rows) {
     Batch& b = bt_;
     const stn_arch& a = a_;
@@ -323,11 +347,12 @@ void Engine::enqueue_after_duration(int total_step, const std::function<void()>&
     };
     struct Disarm { std::function<void()>& g; ~Disarm() { g = nullptr; } } disarm{text_gate_};  // it refers to this frame: never outlives it
     if (a.ve_main_blocks == 0) { auto fire = std::move(text_gate_); text_gate_ = nullptr; fire(); }  // (no cross-attention would ever fire it)
-    float* tot_all = f32_alloc((int64_t)total_step * B);
-    float* cur_all = f32_alloc((int64_t)total_step * B);
-    float* dt_all = f32_alloc(B);
-    launch_step_counters(s_, tot_all, cur_all, dt_all, B, total_step);
-    const float* tb_all = ve_time_cond_dev(total_step * B, tot_all, cur_all);
+    // (step counters and time conditioning: computed once per (total_step, B, weights) by ensure_time_cond, ahead of the captured pipeline)
+    if (tcond_.steps != total_step || tcond_.B != B || tcond_.wgen != wgen_) throw std::runtime_error("time conditioning not prepared for this run");
+    const float* tot_all = tcond_.tot;
+    const float* cur_all = tcond_.cur;
+    const float* dt_all = tcond_.dt;
+    const float* tb_all = tcond_.tb;
     const size_t tb_stride = (size_t)B * a.ve_main_blocks * a.ve_dim;
     Ragged rg;
     const Ragged* rgp = nullptr;
