@@ -433,7 +433,9 @@ def main():
                        "weights": "synthetic (descriptor include/stn_arch.h, seed 7)",
                        "in_flight_batches": 1,
                        "timed_region": f"{args.steps} syntheses of the resident batch as hipGraph replays of the post-duration pipeline ({replays_timed} replays counted); "
-                                       f"{n_warm} untimed warm-up steps (eager, capture, first replay)",
+                                       f"{n_warm} untimed warm-up steps (eager, capture, first replay); every synthesis runs the duration predictor, the text encoder, the noise, "
+                                       "all Euler steps and the vocoder on the uploaded inputs — the one thing computed once per (total_step, batch size, weights) instead of per "
+                                       "synthesis is the estimator's time conditioning, which depends on nothing the caller uploads",
                        "warmup_steps_run": n_warm,
                        "hip_built": rt_info["hip_built"], "hip_runtime": rt_info["hip_runtime"], "torch_in_process": bool(rt_info["torch_preloaded"]),
                        "parallelism": f"utterance-sharded x{world}, RCCL gather of int16 PCM to rank 0 overlapped with the next step" if world > 1 else "single GPU"},
